@@ -1,0 +1,106 @@
+// Device-resident scene layout, re-packed for 16-byte vector loads on gfx950.
+//
+//  * DNode (64 B, half a 128-B line): one interior node holding BOTH child boxes and both
+//    child references, so an interior visit is one 64-B fetch instead of the reference's three
+//    dependent 32-B fetches (parent, then the two children; kernel/intersection.h:54,114-121).
+//    TLAS and BLAS interior nodes share this format and one array.
+//  * DTri (48 B): the three object-space positions of a triangle, stored in leaf order, plus
+//    the triangle's index inside its mesh.  Replaces the tri_indices -> indices -> positions
+//    chain and the eager normal/uv fetch of kernel/intersection.h:67-84.
+//  * DInst (64 B): the 3x4 world->object matrix, the BLAS root reference and the material tag.
+//  * DInstFwd (112 B): object->world and inverse-transpose matrices plus light fields, read
+//    only when a hit is resolved.
+//
+// Child reference encoding (32 bit):
+//   bit31 = 0          interior: index into the DNode array
+//   bit31 = 1, TLAS    leaf: bits[30:0] = GeometryInstance index
+//   bit31 = 1, BLAS    leaf: bits[30:28] = triangle count - 1 (0..6) and bits[27:0] = first DTri,
+//                      or bits[30:28] = 7 and bits[27:0] = index into big_leaves {first, count}
+//   0x7FFFFFFF         "nothing" (used inside the traversal loop)
+#pragma once
+#include "../../include/ptamd.h"
+#include "dmath.h"
+
+namespace ptd {
+
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kNoRef = 0x7FFFFFFFu;
+constexpr uint32_t kMaxTris = 1u << 28;
+
+struct DNode {
+    float4 a;  // left  min.xyz, w = left  ref bits
+    float4 b;  // left  max.xyz, w = right ref bits
+    float4 c;  // right min.xyz
+    float4 d;  // right max.xyz
+};
+struct DTri {
+    float4 a;  // p0.xyz, p1.x
+    float4 b;  // p1.yz, p2.xy
+    float4 c;  // p2.z, bits(triangle index in mesh), 0, 0
+};
+struct DInst {
+    float4 a;  // inv_transform c0.xyz, c1.x
+    float4 b;  // c1.yz, c2.xy
+    float4 c;  // c2.z, c3.xyz
+    float4 d;  // bits: root ref, material id, material type, mesh first_index
+};
+struct DInstFwd {
+    float4 t0, t1, t2;  // transform columns c0..c3 packed as 12 floats
+    float4 n0, n1, n2;  // inv_transpose columns c0..c3 packed as 12 floats
+    float4 m;           // total_area, bits(area_light_id), bits(triangle_sampler_index), bits(material_id)
+};
+// Unified texture descriptor for Texture<float> and Texture<glm::vec3>.
+struct DTex {
+    int32_t type;
+    int32_t image_id;
+    float scale[2], offset[2];
+    float c0[3], c1[3];  // constant value / checkerboard colours (scalar textures use [0])
+    int32_t width, height;
+};
+struct DImage {
+    const void *data;  // float (1 channel) or float4 (3 channels + padding)
+    int32_t width, height;
+};
+struct DAlias {
+    const float *prob;
+    const uint32_t *alias;
+    uint32_t size;
+    uint32_t _pad;
+};
+struct DMaterial {  // pt_material bit layout
+    uint32_t type;   // low byte
+    int32_t tex0;
+    uint32_t w1;     // float or int bits
+    int32_t w2;
+};
+struct DCamera {
+    int32_t res_x, res_y;
+    float px, py;  // pixel_length
+    float focal_length;
+    V3 position, front, up, right;
+};
+
+struct DScene {
+    const DNode *nodes;
+    const DTri *tris;
+    const DInst *insts;
+    const DInstFwd *fwd;
+    const uint2 *big_leaves;
+    const uint32_t *indices;
+    const float *positions, *normals, *uvs;
+    const DMaterial *materials;
+    const DTex *tex1, *tex3;
+    const DImage *images1, *images3;
+    const pt_area_light *lights;
+    const DAlias *tri_samplers;
+    DAlias light_sampler;
+    uint32_t tex1_count, tex3_count, image1_count, image3_count;
+    uint32_t light_count, material_count, geometry_count;
+    uint32_t root_ref;
+    float root_min[3], root_max[3];
+    uint32_t max_depth;
+    float total_light_power;
+    DCamera camera;
+};
+
+}  // namespace ptd

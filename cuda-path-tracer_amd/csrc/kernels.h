@@ -1,0 +1,489 @@
+// Wavefront path-tracing kernels for gfx950 (wave64).  One sample per pixel per iteration:
+//   k_generate -> [ k_extend -> k_shade -> k_shadow ] x max_depth -> k_film (-> k_tonemap)
+// Queues hold path slots; appends are wave-aggregated (one atomic per wave and queue, ballot +
+// mbcnt prefix), and every queue consumer is a persistent grid whose waves fetch 64-entry
+// chunks through a global cursor, so no launch depends on a host-side read of a counter.
+//
+// Reference: kernel/integrators/path_trace.cu:76-434 (GenerateRaysKernel, IntersectClosestKernel,
+// MaterialShadeKernel<M>, EmissiveHitKernel, FinalGather, PostprocessAndUpload).
+#pragma once
+#include "shade.h"
+
+namespace ptd {
+
+constexpr int kNumClasses = 5;  // 0 = emissive hit or miss, 1 lambertian, 2 mirror, 3 metallic-roughness, 4 dielectric
+
+// Per-bounce counters, 64 B, zeroed once per iteration for all bounces.
+struct BounceCounters {
+    uint32_t ext_count;               // extension rays entering this bounce
+    uint32_t class_count[kNumClasses];
+    uint32_t shadow_count;
+    uint32_t cur_extend, cur_shade, cur_shadow;  // work-fetch cursors
+    uint32_t _pad[6];
+};
+
+struct DevStats {
+    uint32_t spills, drops, nan_pixels, _pad;
+};
+
+struct PathState {
+    float4 *ray_o;     // origin.xyz, last_pdf
+    float4 *ray_d;     // direction.xyz, bits(remaining_bounces)
+    float4 *thr;       // throughput.xyz
+    float4 *accum;     // accumulated radiance.xyz
+    float4 *last_pos;  // last surface position.xyz
+    uint2 *rng;        // PCG state
+    float4 *hit;       // t, u, v, bits(triangle record)
+    int *hit_inst;
+    float4 *sh_o;      // shadow ray origin.xyz, tmax        (indexed by shadow-queue slot)
+    float4 *sh_d;      // shadow ray direction.xyz, bits(path slot)
+    float4 *sh_c;      // contribution added when unoccluded
+    uint32_t *ext_q[2];
+    uint32_t *class_q[kNumClasses];
+    uint32_t capacity;  // path slots (pixels padded to 8x8 tiles)
+};
+
+// One atomic per wave: lanes with `pred` receive consecutive slots of the queue behind `counter`.
+// Must be reached by all 64 lanes of the wave.
+PTD uint32_t wave_append(uint32_t *counter, bool pred) {
+    const uint64_t mask = __ballot(pred);
+    if (mask == 0) return 0;
+    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+    const int leader = __ffsll((unsigned long long)mask) - 1;
+    uint32_t base = 0;
+    if (int(threadIdx.x & 63) == leader) base = atomicAdd(counter, uint32_t(__popcll(mask)));
+    base = __shfl(base, leader, 64);
+    return base + prefix;
+}
+
+// Fetches the next 64-entry chunk index for the calling wave (wave-uniform result).
+PTD uint32_t wave_fetch(uint32_t *cursor, uint32_t amount) {
+    uint32_t v = 0;
+    if ((threadIdx.x & 63) == 0) v = atomicAdd(cursor, amount);
+    return __shfl(v, 0, 64);
+}
+
+PTD void flush_events(DevStats *stats, const LaneEvents &ev) {
+    if (ev.spills) atomicAdd(&stats->spills, ev.spills);
+    if (ev.drops) atomicAdd(&stats->drops, ev.drops);
+}
+
+// ------------------------------------------------------------- batch queries
+template <bool COUNT>
+__global__ __launch_bounds__(64) void k_trace_closest(DScene S, const pt_ray *rays, uint32_t n, pt_hit *hits, uint32_t *cursor,
+                                                      uint2 *spill, uint32_t spill_stride, DevStats *stats, TraceCounters *counters) {
+    __shared__ uint2 lds[kLdsDepth * kWave];
+    const uint32_t lane = threadIdx.x;
+    const LaneStack stk{lds + lane, spill + size_t(blockIdx.x) * kWave + lane, spill_stride};
+    LaneEvents ev;
+    for (;;) {
+        const uint32_t base = wave_fetch(cursor, kWave);
+        if (base >= n) break;
+        const uint32_t i = base + lane;
+        if (i < n) {
+            const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
+            const float4 ro = rp[0], rd = rp[1];
+            HitRec h;
+            TraceCounters c{0, 0, 0, 0};
+            const bool hit = trace_ray<MODE_CLOSEST, COUNT>(S, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), rd.w, stk, h, ev, c);
+            int prim = -1, mat = -1;
+            if (hit) {
+                prim = int(as_u(reinterpret_cast<const float4 *>(S.tris + h.rec)[2].y));
+                mat = int(as_u(reinterpret_cast<const float4 *>(S.insts + h.inst)[3].y));
+            }
+            float4 *hp = reinterpret_cast<float4 *>(hits + i);
+            hp[0] = make_float4(hit ? h.t : -1.0f, hit ? h.u : 0.0f, hit ? h.v : 0.0f, as_f(uint32_t(prim)));
+            hp[1] = make_float4(as_f(uint32_t(hit ? h.inst : -1)), as_f(uint32_t(mat)), 0.0f, 0.0f);
+            if (COUNT) counters[i] = c;
+        }
+    }
+    flush_events(stats, ev);
+}
+
+__global__ __launch_bounds__(64) void k_trace_any(DScene S, const pt_ray *rays, uint32_t n, uint8_t *occluded, uint32_t *cursor,
+                                                  uint2 *spill, uint32_t spill_stride, DevStats *stats) {
+    __shared__ uint2 lds[kLdsDepth * kWave];
+    const uint32_t lane = threadIdx.x;
+    const LaneStack stk{lds + lane, spill + size_t(blockIdx.x) * kWave + lane, spill_stride};
+    LaneEvents ev;
+    for (;;) {
+        const uint32_t base = wave_fetch(cursor, kWave);
+        if (base >= n) break;
+        const uint32_t i = base + lane;
+        if (i < n) {
+            const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
+            const float4 ro = rp[0], rd = rp[1];
+            HitRec h;
+            TraceCounters c{0, 0, 0, 0};
+            const bool hit = trace_ray<MODE_ANY, false>(S, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), rd.w, stk, h, ev, c);
+            occluded[i] = hit ? 1 : 0;
+        }
+    }
+    flush_events(stats, ev);
+}
+
+__global__ void k_resolve_hits(DScene S, const pt_ray *rays, const pt_hit *hits, uint32_t n, pt_intersection *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const pt_hit h = hits[i];
+    pt_intersection r;
+    r.time = -1.0f;
+    r.pos[0] = r.pos[1] = r.pos[2] = 0.0f;
+    r.normal[0] = r.normal[1] = r.normal[2] = 0.0f;
+    r.uv[0] = r.uv[1] = 0.0f;
+    r.material_id = -1;
+    r.geometry_id = -1;
+    if (h.inst >= 0 && uint32_t(h.inst) < S.geometry_count) {
+        // find the triangle record of (instance, prim): records of a mesh are a permutation, so
+        // the resolve kernel interpolates from the mesh arrays directly
+        const float4 id = reinterpret_cast<const float4 *>(S.insts + h.inst)[3];
+        const uint32_t first_index = as_u(id.w);
+        const uint32_t i0 = S.indices[first_index + uint32_t(h.prim) * 3u + 0], i1 = S.indices[first_index + uint32_t(h.prim) * 3u + 1],
+                       i2 = S.indices[first_index + uint32_t(h.prim) * 3u + 2];
+        const V3 p0 = ld3(S.positions, i0), p1 = ld3(S.positions, i1), p2 = ld3(S.positions, i2);
+        const V3 n0 = ld3(S.normals, i0), n1 = ld3(S.normals, i1), n2 = ld3(S.normals, i2);
+        const V2 uv0 = ld2(S.uvs, i0), uv1 = ld2(S.uvs, i1), uv2 = ld2(S.uvs, i2);
+        const float w = 1.0f - h.u - h.v;
+        const V3 bn = normalize(w * n0 + h.u * n1 + h.v * n2);
+        const V2 buv = w * uv0 + h.u * uv1 + h.v * uv2;
+        const V3 bp = w * p0 + h.u * p1 + h.v * p2;
+        const float4 *fp = reinterpret_cast<const float4 *>(S.fwd + h.inst);
+        const M34 T = load_m34(fp[0], fp[1], fp[2]);
+        const M34 N = load_m34(fp[3], fp[4], fp[5]);
+        const V3 pos = xform(T, bp, 1.0f);
+        const V3 nrm = normalize(xform(N, bn, 0.0f));
+        const V3 ro = mk3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]);
+        const V3 rd = mk3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]);
+        r.time = dot(pos - ro, rd);
+        r.pos[0] = pos.x; r.pos[1] = pos.y; r.pos[2] = pos.z;
+        r.normal[0] = nrm.x; r.normal[1] = nrm.y; r.normal[2] = nrm.z;
+        r.uv[0] = buv.x; r.uv[1] = buv.y;
+        r.material_id = int(as_u(id.y));
+        r.geometry_id = h.inst;
+    }
+    out[i] = r;
+}
+
+// Incoherent rays: origin uniform in the root box scaled 1.1x about its centre, direction
+// uniform on the sphere, PCG state (i << 32) | 0xdeadbeef.
+__global__ void k_gen_incoherent(DScene S, pt_ray *rays, uint32_t n, uint64_t first_index) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint64_t rng = ((first_index + k) << 32) | 0xdeadbeefull;
+    float o[3];
+    for (int a = 0; a < 3; ++a) {
+        const float c = 0.5f * (S.root_min[a] + S.root_max[a]);
+        const float hw = 0.55f * (S.root_max[a] - S.root_min[a]);
+        const float xi = sample1d(rng);
+        o[a] = c + hw * (2.0f * xi - 1.0f);
+    }
+    const float z = 1.0f - 2.0f * sample1d(rng);
+    const float phi = 2.0f * kPi * sample1d(rng);
+    const float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+    float4 *rp = reinterpret_cast<float4 *>(rays + k);
+    rp[0] = make_float4(o[0], o[1], o[2], 0.0f);
+    rp[1] = make_float4(r * cosf(phi), r * sinf(phi), z, FLT_MAX);
+}
+
+// ------------------------------------------------------------ path pipeline
+// Path slot <-> pixel: slots are laid out in 8x8 pixel tiles (one tile per wave) so that the
+// camera rays of a wave form a compact bundle.
+PTD bool slot_to_pixel(uint32_t slot, int width, int height, int &x, int &y) {
+    const uint32_t tiles_x = uint32_t(width + 7) >> 3;
+    const uint32_t tile = slot >> 6, within = slot & 63u;
+    x = int((tile % tiles_x) * 8u + (within & 7u));
+    y = int((tile / tiles_x) * 8u + (within >> 3));
+    return x < width && y < height;
+}
+
+// GenerateRaysKernel, path_trace.cu:76-108.
+__global__ __launch_bounds__(64) void k_generate(DScene S, PathState P, BounceCounters *cnt, int iteration, int width, int height) {
+    const uint32_t slot = blockIdx.x * kWave + threadIdx.x;
+    int x, y;
+    const bool active = slot_to_pixel(slot, width, height, x, y);
+    if (active) {
+        uint64_t rng = seed_sampler(x, y, iteration);
+        const float sx = sample1d(rng), sy = sample1d(rng);
+        sample1d(rng);  // Sample4D draws four values; the lens pair is unused by the pinhole camera
+        sample1d(rng);
+        const DCamera &c = S.camera;  // SpawnCameraRay, kernel/camera.h:10-22
+        const float fx = ((float(x) + sx) - 0.5f * float(c.res_x)) * c.px;
+        const float fy = ((float(y) + sy) - 0.5f * float(c.res_y)) * c.py;
+        const V3 film_point = c.position + c.front * c.focal_length + c.right * fx - c.up * fy;
+        const V3 dir = normalize(film_point - c.position);
+        P.ray_o[slot] = make_float4(c.position.x, c.position.y, c.position.z, -1.0f);
+        P.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, as_f(S.max_depth));
+        P.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        P.accum[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        P.rng[slot] = make_uint2(uint32_t(rng), uint32_t(rng >> 32));
+    }
+    const uint32_t q = wave_append(&cnt[0].ext_count, active);
+    if (active) P.ext_q[0][q] = slot;
+}
+
+// IntersectClosestKernel, path_trace.cu:110-179: closest hit + classification by material type.
+__global__ __launch_bounds__(64) void k_extend(DScene S, PathState P, BounceCounters *cnt, int bounce, uint2 *spill,
+                                               uint32_t spill_stride, DevStats *stats) {
+    __shared__ uint2 lds[kLdsDepth * kWave];
+    const uint32_t lane = threadIdx.x;
+    const LaneStack stk{lds + lane, spill + size_t(blockIdx.x) * kWave + lane, spill_stride};
+    BounceCounters *bc = cnt + bounce;
+    const uint32_t n = bc->ext_count;
+    const uint32_t *queue = P.ext_q[bounce & 1];
+    LaneEvents ev;
+    for (;;) {
+        const uint32_t base = wave_fetch(&bc->cur_extend, kWave);
+        if (base >= n) break;
+        const uint32_t qi = base + lane;
+        const bool active = qi < n;
+        int cls = -1;
+        uint32_t slot = 0;
+        if (active) {
+            slot = queue[qi];
+            const float4 ro = P.ray_o[slot], rd = P.ray_d[slot];
+            HitRec h;
+            TraceCounters c{0, 0, 0, 0};
+            const bool hit = trace_ray<MODE_CLOSEST, false>(S, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), FLT_MAX, stk, h, ev, c);
+            P.hit[slot] = make_float4(h.t, h.u, h.v, as_f(h.rec));
+            P.hit_inst[slot] = hit ? h.inst : -1;
+            cls = 0;
+            if (hit) {
+                const uint32_t type = as_u(reinterpret_cast<const float4 *>(S.insts + h.inst)[3].z);
+                cls = type == PT_MAT_LAMBERTIAN ? 1 : type == PT_MAT_MIRROR ? 2 : type == PT_MAT_METALLIC_ROUGHNESS ? 3
+                      : type == PT_MAT_DIELECTRIC ? 4 : 0;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kNumClasses; ++k) {
+            const bool mine = active && cls == k;
+            const uint32_t q = wave_append(&bc->class_count[k], mine);
+            if (mine) P.class_q[k][q] = slot;
+        }
+    }
+    flush_events(stats, ev);
+}
+
+// MaterialShadeKernel<M> (path_trace.cu:181-290) for classes 1..4 and EmissiveHitKernel
+// (:337-389) for class 0, as one persistent launch whose waves each work on a single class.
+// Next-event estimation is split off: the light sample and its full contribution are computed
+// here, the visibility test runs in k_shadow, which adds the contribution when unoccluded.
+__global__ __launch_bounds__(64) void k_shade(DScene S, PathState P, BounceCounters *cnt, int bounce) {
+    const uint32_t lane = threadIdx.x;
+    BounceCounters *bc = cnt + bounce;
+    uint32_t chunk_start[kNumClasses + 1];
+    chunk_start[0] = 0;
+#pragma unroll
+    for (int k = 0; k < kNumClasses; ++k) chunk_start[k + 1] = chunk_start[k] + ((bc->class_count[k] + kWave - 1) >> 6);
+    const uint32_t total_chunks = chunk_start[kNumClasses];
+    for (;;) {
+        const uint32_t chunk = wave_fetch(&bc->cur_shade, 1);
+        if (chunk >= total_chunks) break;
+        int cls = 0;
+#pragma unroll
+        for (int k = 1; k < kNumClasses; ++k)
+            if (chunk >= chunk_start[k]) cls = k;
+        const uint32_t qi = (chunk - chunk_start[cls]) * kWave + lane;
+        const bool active = qi < bc->class_count[cls];
+        bool want_shadow = false, want_extend = false;
+        uint32_t slot = 0;
+        float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_c = sh_o;
+        if (active) {
+            slot = P.class_q[cls][qi];
+            const float4 ro4 = P.ray_o[slot], rd4 = P.ray_d[slot];
+            const V3 ro = mk3(ro4.x, ro4.y, ro4.z), rd = mk3(rd4.x, rd4.y, rd4.z);
+            const float last_pdf = ro4.w;
+            int remaining_bounces = int(as_u(rd4.w));
+            const float4 thr4 = P.thr[slot];
+            V3 throughput = mk3(thr4.x, thr4.y, thr4.z);
+            const float4 acc4 = P.accum[slot];
+            V3 accum = mk3(acc4.x, acc4.y, acc4.z);
+            const int inst = P.hit_inst[slot];
+            if (cls == 0) {
+                if (inst < 0) {
+                    accum = accum + throughput * splat(0.0f);  // black environment, path_trace.cu:351-356
+                } else {
+                    const float4 h4 = P.hit[slot];
+                    const Isect is = resolve_hit(S, ro, rd, h4.y, h4.z, as_u(h4.w), inst);
+                    const DMaterial m = S.materials[is.material_id];
+                    const float4 fm = reinterpret_cast<const float4 *>(S.fwd + inst)[6];
+                    const V3 color = sample_tex3(S, m.tex0, is.uv);
+                    const V3 radiance = as_f(m.w1) * color;
+                    float weight_bsdf = 1.0f;
+                    if (last_pdf > 0.0f) {
+                        const float4 lp4 = P.last_pos[slot];
+                        const V3 surface_point = mk3(lp4.x, lp4.y, lp4.z);
+                        const pt_area_light light = S.lights[int(as_u(fm.y))];
+                        const float dist2 = length2(is.pos - surface_point);
+                        const V3 w_in = normalize(surface_point - is.pos);
+                        const float cos_light = dot(is.normal, w_in);
+                        if (cos_light > 0.0f) {
+                            const float light_pdf = (light.power / S.total_light_power) * (1.0f / fm.x) * dist2 / cos_light;
+                            weight_bsdf = power_heuristic(last_pdf, light_pdf);
+                        }
+                    }
+                    accum = accum + throughput * radiance * weight_bsdf;
+                }
+                P.accum[slot] = make_float4(accum.x, accum.y, accum.z, 0.0f);
+            } else {
+                const float4 h4 = P.hit[slot];
+                const Isect is = resolve_hit(S, ro, rd, h4.y, h4.z, as_u(h4.w), inst);
+                const DMaterial m = S.materials[is.material_id];
+                const uint32_t mtype = m.type & 0xFFu;
+                const uint2 r2 = P.rng[slot];
+                uint64_t rng = uint64_t(r2.x) | (uint64_t(r2.y) << 32);
+                const V3 w_out = -normalize(rd);
+                const bool specular = (mtype == PT_MAT_MIRROR || mtype == PT_MAT_DIELECTRIC);
+                if (!specular && S.light_count > 0) {
+                    const LightSample ls = sample_scene_light(S, rng);
+                    const V3 w_in = normalize(ls.position - is.pos);
+                    const float dist = length(is.pos - ls.position);
+                    const float cos_surf = dot(is.normal, w_in);
+                    const float cos_light = dot(ls.normal, -w_in);
+                    if (cos_surf > 0.0f && cos_light > 0.0f) {
+                        V3 bsdf;
+                        float bsdf_pdf;
+                        if (mtype == PT_MAT_LAMBERTIAN) {
+                            bsdf = sample_tex3(S, m.tex0, is.uv) * kInvPi;
+                            bsdf_pdf = fmaxf(0.0f, dot(is.normal, w_in)) * kInvPi;
+                        } else {
+                            bsdf = eval_metallic_roughness(S, m, is, w_in, w_out);
+                            bsdf_pdf = metallic_roughness_pdf(S, m, is, w_in, w_out);
+                        }
+                        const float light_pdf = ls.pdf * dist * dist / cos_light;
+                        const float light_weight = power_heuristic(light_pdf, bsdf_pdf);
+                        const V3 contrib = throughput * light_weight * bsdf * cos_surf * ls.radiance / light_pdf;
+                        const V3 so = is.pos + kEps * w_in;
+                        const float tmax = float(double(dist) - 1e-4);  // path_trace.cu:228
+                        sh_o = make_float4(so.x, so.y, so.z, tmax);
+                        sh_d = make_float4(w_in.x, w_in.y, w_in.z, as_f(slot));
+                        sh_c = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
+                        want_shadow = true;
+                    }
+                }
+                BsdfSample sample;
+                if (mtype == PT_MAT_LAMBERTIAN) sample = sample_lambertian(S, m, is, rng);
+                else if (mtype == PT_MAT_MIRROR) sample = sample_mirror(S, m, is, w_out);
+                else if (mtype == PT_MAT_DIELECTRIC) sample = sample_dielectric(S, m, is, w_out, rng);
+                else sample = sample_metallic_roughness(S, m, is, w_out, rng);
+                const float cos_surf = fabsf(dot(is.normal, sample.w_in));
+                bool alive = !(sample.pdf < kEps || cos_surf < kEps || sample.type == S_Invalid);
+                float new_last_pdf = last_pdf;
+                if (alive) {
+                    throughput = throughput * (sample.bsdf * cos_surf / sample.pdf);
+                    new_last_pdf = specular ? -1.0f : sample.pdf;
+                    P.last_pos[slot] = make_float4(is.pos.x, is.pos.y, is.pos.z, 0.0f);
+                    const float bounces = float(S.max_depth - uint32_t(remaining_bounces));
+                    if (bounces >= 3) {  // Russian roulette, path_trace.cu:263-277
+                        const float survival = gmin(gmax(luminance(throughput), 0.05f), 0.95f);
+                        if (sample1d(rng) >= survival) {
+                            remaining_bounces = 0;
+                            alive = false;
+                        } else {
+                            throughput = throughput / survival;
+                        }
+                    }
+                }
+                V3 no = ro, nd = rd;
+                if (alive) {
+                    no = is.pos + kEps * sample.w_in;
+                    nd = sample.w_in;
+                    remaining_bounces--;
+                    want_extend = remaining_bounces > 0;
+                }
+                P.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, 0.0f);
+                P.ray_o[slot] = make_float4(no.x, no.y, no.z, new_last_pdf);
+                P.ray_d[slot] = make_float4(nd.x, nd.y, nd.z, as_f(uint32_t(remaining_bounces)));
+                P.rng[slot] = make_uint2(uint32_t(rng), uint32_t(rng >> 32));
+            }
+        }
+        const uint32_t sq = wave_append(&bc->shadow_count, want_shadow);
+        if (want_shadow) {
+            P.sh_o[sq] = sh_o;
+            P.sh_d[sq] = sh_d;
+            P.sh_c[sq] = sh_c;
+        }
+        const uint32_t eq = wave_append(&bc[1].ext_count, want_extend);
+        if (want_extend) P.ext_q[(bounce + 1) & 1][eq] = slot;
+    }
+}
+
+// The visibility half of next-event estimation (path_trace.cu:221-243): IntersectScene<ANY> with
+// t_max = dist - 1e-4; an unoccluded sample adds its contribution to the path's radiance.
+__global__ __launch_bounds__(64) void k_shadow(DScene S, PathState P, BounceCounters *cnt, int bounce, uint2 *spill,
+                                               uint32_t spill_stride, DevStats *stats) {
+    __shared__ uint2 lds[kLdsDepth * kWave];
+    const uint32_t lane = threadIdx.x;
+    const LaneStack stk{lds + lane, spill + size_t(blockIdx.x) * kWave + lane, spill_stride};
+    BounceCounters *bc = cnt + bounce;
+    const uint32_t n = bc->shadow_count;
+    LaneEvents ev;
+    for (;;) {
+        const uint32_t base = wave_fetch(&bc->cur_shadow, kWave);
+        if (base >= n) break;
+        const uint32_t qi = base + lane;
+        if (qi < n) {
+            const float4 so = P.sh_o[qi], sd = P.sh_d[qi];
+            HitRec h;
+            TraceCounters c{0, 0, 0, 0};
+            const bool occluded = trace_ray<MODE_ANY, false>(S, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, stk, h, ev, c);
+            if (!occluded) {
+                const uint32_t slot = as_u(sd.w);
+                const float4 sc = P.sh_c[qi];
+                float4 a = P.accum[slot];
+                a.x += sc.x;
+                a.y += sc.y;
+                a.z += sc.z;
+                P.accum[slot] = a;
+            }
+        }
+    }
+    flush_events(stats, ev);
+}
+
+// FinalGather, path_trace.cu:391-407: film += sample, NaN samples are dropped (and counted).
+__global__ __launch_bounds__(64) void k_film(PathState P, float *film, int width, int height, DevStats *stats) {
+    const uint32_t slot = blockIdx.x * kWave + threadIdx.x;
+    int x, y;
+    if (!slot_to_pixel(slot, width, height, x, y)) return;
+    float4 a = P.accum[slot];
+    if (isnan(a.x) || isnan(a.y) || isnan(a.z)) {
+        atomicAdd(&stats->nan_pixels, 1u);
+        a = make_float4(0, 0, 0, 0);
+    }
+    float *px = film + 3 * (size_t(y) * width + x);
+    px[0] += a.x;
+    px[1] += a.y;
+    px[2] += a.z;
+}
+
+// PostprocessAndUpload, path_trace.cu:409-434: film / iterations -> ACES -> (int)(p * 255.0), no gamma.
+__global__ void k_tonemap(const float *film, uint8_t *rgba, int width, int height, int iterations) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= uint32_t(width) * uint32_t(height)) return;
+    const float inv = float(iterations);
+    uchar4 o;
+    uint8_t *c = reinterpret_cast<uint8_t *>(&o);
+    for (int k = 0; k < 3; ++k) {
+        const float radiance = film[3 * size_t(i) + k] / inv;
+        const float p = aces(radiance);
+        int v = int(double(p) * 255.0);
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        c[k] = uint8_t(v);
+    }
+    c[3] = 255;
+    reinterpret_cast<uchar4 *>(rgba)[i] = o;
+}
+
+// Copies the extension rays of one bounce into a pt_ray buffer (queue order).
+__global__ void k_gather_rays(PathState P, const BounceCounters *cnt, int bounce, pt_ray *out, uint32_t capacity) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = cnt[bounce].ext_count;
+    if (i >= n || i >= capacity) return;
+    const uint32_t slot = P.ext_q[bounce & 1][i];
+    const float4 ro = P.ray_o[slot], rd = P.ray_d[slot];
+    float4 *rp = reinterpret_cast<float4 *>(out + i);
+    rp[0] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+    rp[1] = make_float4(rd.x, rd.y, rd.z, FLT_MAX);
+}
+
+}  // namespace ptd

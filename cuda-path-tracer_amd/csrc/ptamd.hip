@@ -1,0 +1,1038 @@
+// libptamd.so: implementation of include/ptamd.h for gfx950 (MI355X).
+// Context and device memory management, scene validation and re-packing, kernel launches.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/ptamd.h"
+#include "kernels.h"
+
+using namespace ptd;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct EventPair {
+    hipEvent_t start, stop;
+    int cls;
+};
+enum { EV_CLOSEST = 0, EV_ANY, EV_GENERATE, EV_SHADE, EV_FILM, EV_COUNT };
+
+}  // namespace
+
+struct pt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string error;
+    int num_cus = 256;
+    uint32_t grid_blocks = 0;  // persistent grid size (blocks of one wave)
+
+    // scene
+    bool scene_ready = false;
+    DScene scene;
+    std::vector<void *> scene_allocs;
+
+    // traversal scratch
+    uint2 *spill = nullptr;
+    uint32_t spill_stride = 0;
+    uint32_t *cursor = nullptr;  // work-fetch cursor of the batch queries
+    DevStats *dev_stats = nullptr;
+
+    // integrator
+    bool integrator_ready = false;
+    int width = 0, height = 0;
+    PathState paths;
+    std::vector<void *> path_allocs;
+    float *film = nullptr;
+    BounceCounters *counters = nullptr;
+    uint32_t counters_capacity = 0;  // bounces + 1
+    uint32_t *pinned_word = nullptr;
+    int last_render_bounces = 0;
+
+    // profiling
+    bool profiling = false;
+    std::vector<EventPair> pending;
+    std::vector<EventPair> free_events;
+    pt_stats stats;
+    int trace_mode = 0;
+};
+
+namespace {
+
+int Fail(pt_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->error = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                                  \
+    do {                                                                                                    \
+        hipError_t e__ = (expr);                                                                            \
+        if (e__ != hipSuccess) return Fail(ctx, PT_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        (void)hipGetDevice(&prev);
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+template <typename T>
+int Upload(pt_ctx *ctx, std::vector<void *> &owner, const T *host, size_t count, const T **out) {
+    *out = nullptr;
+    if (count == 0) {
+        // keep a valid (non-null) pointer so kernels never see nullptr arithmetic
+        void *p = nullptr;
+        HIP_TRY(ctx, hipMalloc(&p, 256));
+        owner.push_back(p);
+        *out = static_cast<const T *>(p);
+        return PT_OK;
+    }
+    void *p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, count * sizeof(T)));
+    owner.push_back(p);
+    HIP_TRY(ctx, hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *out = static_cast<const T *>(p);
+    return PT_OK;
+}
+
+template <typename T>
+int Alloc(pt_ctx *ctx, std::vector<void *> &owner, size_t count, T **out) {
+    void *p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    owner.push_back(p);
+    *out = static_cast<T *>(p);
+    return PT_OK;
+}
+
+void FreeAll(std::vector<void *> &owner) {
+    for (void *p : owner) (void)hipFree(p);
+    owner.clear();
+}
+
+// ---------------------------------------------------------------- profiling
+void BeginEvent(pt_ctx *ctx, int cls, EventPair &ev, bool &active) {
+    active = false;
+    if (!ctx->profiling) return;
+    if (!ctx->free_events.empty()) {
+        ev = ctx->free_events.back();
+        ctx->free_events.pop_back();
+    } else {
+        if (hipEventCreate(&ev.start) != hipSuccess) return;
+        if (hipEventCreate(&ev.stop) != hipSuccess) return;
+    }
+    ev.cls = cls;
+    (void)hipEventRecord(ev.start, ctx->stream);
+    active = true;
+}
+void EndEvent(pt_ctx *ctx, EventPair &ev, bool active) {
+    if (!active) return;
+    (void)hipEventRecord(ev.stop, ctx->stream);
+    ctx->pending.push_back(ev);
+}
+void DrainEvents(pt_ctx *ctx) {
+    for (EventPair &ev : ctx->pending) {
+        (void)hipEventSynchronize(ev.stop);
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ev.start, ev.stop) == hipSuccess) {
+            switch (ev.cls) {
+                case EV_CLOSEST: ctx->stats.ms_closest += ms; ctx->stats.n_closest++; break;
+                case EV_ANY: ctx->stats.ms_any += ms; ctx->stats.n_any++; break;
+                case EV_GENERATE: ctx->stats.ms_generate += ms; ctx->stats.n_generate++; break;
+                case EV_SHADE: ctx->stats.ms_shade += ms; ctx->stats.n_shade++; break;
+                case EV_FILM: ctx->stats.ms_film += ms; ctx->stats.n_film++; break;
+            }
+        }
+        ctx->free_events.push_back(ev);
+    }
+    ctx->pending.clear();
+}
+struct ScopedEvent {
+    pt_ctx *ctx;
+    EventPair ev;
+    bool active;
+    ScopedEvent(pt_ctx *c, int cls) : ctx(c) { BeginEvent(c, cls, ev, active); }
+    ~ScopedEvent() { EndEvent(ctx, ev, active); }
+};
+
+// ------------------------------------------------------------ scene re-pack
+bool FiniteBox(const float *mn, const float *mx) {
+    for (int a = 0; a < 3; ++a)
+        if (!(mn[a] == mn[a]) || !(mx[a] == mx[a])) return false;
+    return true;
+}
+
+int Validate(pt_ctx *ctx, const pt_scene_desc *d) {
+    if (!d) return Fail(ctx, PT_ERR_INVALID, "scene description is null");
+    if (d->max_depth < 1) return Fail(ctx, PT_ERR_INVALID, "max_depth must be >= 1");
+    if (d->max_depth > 4096) return Fail(ctx, PT_ERR_LIMIT, "max_depth %u exceeds the limit of 4096", d->max_depth);
+    if (d->vertex_count == 0 || !d->positions || !d->normals || !d->uvs) return Fail(ctx, PT_ERR_INVALID, "scene has no vertices");
+    if (d->index_count == 0 || !d->indices) return Fail(ctx, PT_ERR_INVALID, "scene has no indices");
+    if (d->geometry_count == 0 || !d->geometries) return Fail(ctx, PT_ERR_INVALID, "scene has no geometry instances");
+    if (d->tlas_node_count == 0 || !d->tlas_nodes) return Fail(ctx, PT_ERR_INVALID, "scene has no TLAS nodes");
+    if (d->blas_count == 0 || !d->blases || d->blas_node_count == 0 || !d->blas_nodes) return Fail(ctx, PT_ERR_INVALID, "scene has no BLAS");
+    if (!d->tri_indices || d->tri_index_count == 0) return Fail(ctx, PT_ERR_INVALID, "scene has no BLAS triangle indices");
+    if (d->tri_index_count >= kMaxTris) return Fail(ctx, PT_ERR_LIMIT, "more than 2^28 BLAS triangles");
+    if (d->material_count == 0 || !d->materials) return Fail(ctx, PT_ERR_INVALID, "scene has no materials");
+    if (d->light_count > 0 && (!d->lights || !d->light_sampler || !d->triangle_samplers))
+        return Fail(ctx, PT_ERR_INVALID, "lights without sampler tables");
+    if (d->camera.resolution[0] <= 0 || d->camera.resolution[1] <= 0) return Fail(ctx, PT_ERR_INVALID, "camera resolution must be positive");
+    for (uint32_t i = 0; i < d->index_count; ++i)
+        if (d->indices[i] >= d->vertex_count) return Fail(ctx, PT_ERR_INVALID, "vertex index %u out of range at %u", d->indices[i], i);
+    for (uint32_t i = 0; i < d->tlas_node_count; ++i) {
+        const pt_tlas_node &n = d->tlas_nodes[i];
+        if (n.left_right == 0) {
+            if (n.instance >= d->geometry_count) return Fail(ctx, PT_ERR_INVALID, "TLAS leaf %u names instance %u", i, n.instance);
+        } else {
+            const uint32_t l = n.left_right & 0xFFFFu, r = n.left_right >> 16;
+            if (l >= d->tlas_node_count || r >= d->tlas_node_count || l == 0 || r == 0 || l == i || r == i)
+                return Fail(ctx, PT_ERR_INVALID, "TLAS node %u has bad children", i);
+        }
+    }
+    for (uint32_t i = 0; i < d->blas_count; ++i) {
+        const pt_blas &b = d->blases[i];
+        if (b.node_count == 0) continue;
+        if (uint64_t(b.first_node) + b.node_count > d->blas_node_count || uint64_t(b.first_index) + b.index_count > d->tri_index_count)
+            return Fail(ctx, PT_ERR_INVALID, "BLAS %u exceeds the node / index arrays", i);
+        for (uint32_t k = b.first_node; k < b.first_node + b.node_count; ++k) {
+            const pt_bvh_node &n = d->blas_nodes[k];
+            if (n.primitive_count > 0) {
+                if (uint64_t(n.first_primitive) + n.primitive_count > b.index_count)
+                    return Fail(ctx, PT_ERR_INVALID, "BLAS %u leaf %u exceeds its triangle range", i, k);
+            } else if (n.first_primitive <= k || uint64_t(n.first_primitive) + 1 >= uint64_t(b.first_node) + b.node_count) {
+                return Fail(ctx, PT_ERR_INVALID, "BLAS %u node %u has bad children", i, k);
+            }
+        }
+    }
+    for (uint32_t i = 0; i < d->geometry_count; ++i) {
+        const pt_geometry_instance &g = d->geometries[i];
+        if (g.material_id < 0 || uint32_t(g.material_id) >= d->material_count) return Fail(ctx, PT_ERR_INVALID, "instance %u: bad material", i);
+        if (g.blas_index < 0 || uint32_t(g.blas_index) >= d->blas_count || d->blases[g.blas_index].node_count == 0)
+            return Fail(ctx, PT_ERR_INVALID, "instance %u: bad blas_index", i);
+        if (g.index_count == 0 || g.index_count % 3 || uint64_t(g.first_index) + g.index_count > d->index_count)
+            return Fail(ctx, PT_ERR_INVALID, "instance %u: bad index range", i);
+        if (g.index_count / 3 != d->blases[g.blas_index].index_count)
+            return Fail(ctx, PT_ERR_INVALID, "instance %u: triangle count differs from its BLAS", i);
+        const uint8_t mt = d->materials[g.material_id].type;
+        if (mt == PT_MAT_EMISSIVE) {
+            if (g.area_light_id < 0 || uint32_t(g.area_light_id) >= d->light_count || g.triangle_sampler_index < 0 ||
+                uint32_t(g.triangle_sampler_index) >= d->triangle_sampler_count)
+                return Fail(ctx, PT_ERR_INVALID, "emissive instance %u lacks light tables", i);
+        }
+    }
+    for (uint32_t i = 0; i < d->material_count; ++i)
+        if (d->materials[i].type > PT_MAT_EMISSIVE) return Fail(ctx, PT_ERR_INVALID, "material %u: unknown type", i);
+    for (uint32_t i = 0; i < d->light_count; ++i) {
+        const int gi = d->lights[i].geometry_instance_index;
+        if (gi < 0 || uint32_t(gi) >= d->geometry_count) return Fail(ctx, PT_ERR_INVALID, "light %u: bad instance", i);
+    }
+    if (d->light_count > 0) {
+        if (d->light_sampler->size != d->light_count) return Fail(ctx, PT_ERR_INVALID, "light sampler size differs from light count");
+        for (uint32_t i = 0; i < d->triangle_sampler_count; ++i)
+            if (d->triangle_samplers[i].size == 0 || !d->triangle_samplers[i].alias_table || !d->triangle_samplers[i].probability_table)
+                return Fail(ctx, PT_ERR_INVALID, "triangle sampler %u is empty", i);
+    }
+    if (!FiniteBox(d->tlas_nodes[0].min, d->tlas_nodes[0].max)) return Fail(ctx, PT_ERR_INVALID, "TLAS root bounds are NaN");
+    return PT_OK;
+}
+
+uint32_t EncodeLeaf(uint32_t first, uint32_t count, std::vector<uint2> &big) {
+    if (count <= 7) return kLeafBit | ((count - 1) << 28) | first;
+    big.push_back(make_uint2(first, count));
+    return kLeafBit | (7u << 28) | uint32_t(big.size() - 1);
+}
+
+void SetNodeChild(DNode &n, int side, const float *mn, const float *mx, uint32_t ref) {
+    if (side == 0) {
+        n.a = make_float4(mn[0], mn[1], mn[2], __builtin_bit_cast(float, ref));
+        n.b.x = mx[0]; n.b.y = mx[1]; n.b.z = mx[2];
+    } else {
+        n.c = make_float4(mn[0], mn[1], mn[2], 0.0f);
+        n.d = make_float4(mx[0], mx[1], mx[2], 0.0f);
+        n.b.w = __builtin_bit_cast(float, ref);
+    }
+}
+
+int FreeScene(pt_ctx *ctx) {
+    FreeAll(ctx->scene_allocs);
+    ctx->scene_ready = false;
+    std::memset(&ctx->scene, 0, sizeof(ctx->scene));
+    return PT_OK;
+}
+
+void FillCamera(DCamera &c, const pt_camera &h) {
+    c.res_x = h.resolution[0];
+    c.res_y = h.resolution[1];
+    c.px = h.pixel_length[0];
+    c.py = h.pixel_length[1];
+    c.focal_length = h.focal_length;
+    c.position = V3{h.position[0], h.position[1], h.position[2]};
+    c.front = V3{h.front[0], h.front[1], h.front[2]};
+    c.up = V3{h.up[0], h.up[1], h.up[2]};
+    c.right = V3{h.right[0], h.right[1], h.right[2]};
+}
+
+int EnsureScratch(pt_ctx *ctx) {
+    if (ctx->spill) return PT_OK;
+    ctx->spill_stride = ctx->grid_blocks * kWave;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->spill), size_t(ctx->spill_stride) * kSpillDepth * sizeof(uint2)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->cursor), 256));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->dev_stats), sizeof(DevStats)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dev_stats, 0, sizeof(DevStats), ctx->stream));
+    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->pinned_word), 64, hipHostMallocDefault));
+    return PT_OK;
+}
+
+}  // namespace
+
+// =========================================================================== API
+extern "C" {
+
+const char *pt_version(void) { return "ptamd 0.1 (gfx950)"; }
+
+const char *pt_last_error(const pt_ctx *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int pt_ctx_create(int device, pt_ctx **out) {
+    if (!out) return Fail(nullptr, PT_ERR_INVALID, "pt_ctx_create: out is null");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) return Fail(nullptr, PT_ERR_DEVICE, "no HIP device available: %s", hipGetErrorString(e));
+    if (device < 0 || device >= count) return Fail(nullptr, PT_ERR_INVALID, "device %d out of range (%d devices)", device, count);
+    pt_ctx *ctx = new pt_ctx();
+    ctx->device = device;
+    std::memset(&ctx->scene, 0, sizeof(ctx->scene));
+    std::memset(&ctx->paths, 0, sizeof(ctx->paths));
+    std::memset(&ctx->stats, 0, sizeof(ctx->stats));
+    DeviceGuard guard(device);
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        delete ctx;
+        return Fail(nullptr, PT_ERR_DEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        delete ctx;
+        return Fail(nullptr, PT_ERR_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    }
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // one wave per block; LDS stack = kLdsDepth*64*8 B per wave -> 160 KiB / 12 KiB = 13 waves per CU
+    const int waves_per_cu = std::min(16, int((160 * 1024) / (kLdsDepth * kWave * sizeof(uint2))));
+    ctx->grid_blocks = uint32_t(ctx->num_cus * waves_per_cu);
+    e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return Fail(nullptr, PT_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return PT_OK;
+}
+
+void pt_ctx_destroy(pt_ctx *ctx) {
+    if (!ctx) return;
+    DeviceGuard guard(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DrainEvents(ctx);
+    for (EventPair &ev : ctx->free_events) {
+        (void)hipEventDestroy(ev.start);
+        (void)hipEventDestroy(ev.stop);
+    }
+    pt_integrator_destroy(ctx);
+    FreeScene(ctx);
+    if (ctx->spill) (void)hipFree(ctx->spill);
+    if (ctx->cursor) (void)hipFree(ctx->cursor);
+    if (ctx->dev_stats) (void)hipFree(ctx->dev_stats);
+    if (ctx->pinned_word) (void)hipHostFree(ctx->pinned_word);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int pt_set_stream(pt_ctx *ctx, void *hip_stream) {
+    if (!ctx) return PT_ERR_INVALID;
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return PT_OK;
+}
+
+int pt_synchronize(pt_ctx *ctx) {
+    if (!ctx) return PT_ERR_INVALID;
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_set_profiling(pt_ctx *ctx, int enabled) {
+    if (!ctx) return PT_ERR_INVALID;
+    ctx->profiling = enabled != 0;
+    return PT_OK;
+}
+
+int pt_set_trace_mode(pt_ctx *ctx, int mode) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (mode != 0) return Fail(ctx, PT_ERR_INVALID, "trace mode %d is not available in this build (0 = reference-exact)", mode);
+    ctx->trace_mode = mode;
+    return PT_OK;
+}
+
+int pt_reset_stats(pt_ctx *ctx) {
+    if (!ctx) return PT_ERR_INVALID;
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    DrainEvents(ctx);
+    std::memset(&ctx->stats, 0, sizeof(ctx->stats));
+    if (ctx->dev_stats) HIP_TRY(ctx, hipMemsetAsync(ctx->dev_stats, 0, sizeof(DevStats), ctx->stream));
+    return PT_OK;
+}
+
+int pt_get_stats(pt_ctx *ctx, pt_stats *out) {
+    if (!ctx || !out) return PT_ERR_INVALID;
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    DrainEvents(ctx);
+    if (ctx->dev_stats) {
+        DevStats ds;
+        HIP_TRY(ctx, hipMemcpy(&ds, ctx->dev_stats, sizeof(ds), hipMemcpyDeviceToHost));
+        ctx->stats.stack_spills = ds.spills;
+        ctx->stats.stack_drops = ds.drops;
+        ctx->stats.nan_pixels = ds.nan_pixels;
+    }
+    if (ctx->integrator_ready && ctx->counters && ctx->last_render_bounces > 0) {
+        std::vector<BounceCounters> bc(size_t(ctx->last_render_bounces) + 1);
+        HIP_TRY(ctx, hipMemcpy(bc.data(), ctx->counters, bc.size() * sizeof(BounceCounters), hipMemcpyDeviceToHost));
+        ctx->stats.closest_rays = 0;
+        ctx->stats.shadow_rays = 0;
+        ctx->stats.bounces_run = 0;
+        std::memset(ctx->stats.queue_sizes, 0, sizeof(ctx->stats.queue_sizes));
+        for (int b = 0; b < ctx->last_render_bounces; ++b) {
+            ctx->stats.closest_rays += bc[b].ext_count;
+            ctx->stats.shadow_rays += bc[b].shadow_count;
+            if (bc[b].ext_count) ctx->stats.bounces_run = uint32_t(b + 1);
+            if (b < PT_MAX_TRACKED_BOUNCES) ctx->stats.queue_sizes[b] = bc[b].ext_count;
+        }
+        ctx->stats.paths = bc[0].ext_count;
+    }
+    *out = ctx->stats;
+    return PT_OK;
+}
+
+// ------------------------------------------------------------------ scene upload
+int pt_scene_free(pt_ctx *ctx) {
+    if (!ctx) return PT_ERR_INVALID;
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return FreeScene(ctx);
+}
+
+int pt_camera_update(pt_ctx *ctx, const pt_camera *camera) {
+    if (!ctx || !camera) return PT_ERR_INVALID;
+    if (!ctx->scene_ready) return Fail(ctx, PT_ERR_STATE, "pt_camera_update before pt_scene_upload");
+    if (camera->resolution[0] <= 0 || camera->resolution[1] <= 0) return Fail(ctx, PT_ERR_INVALID, "camera resolution must be positive");
+    FillCamera(ctx->scene.camera, *camera);
+    return PT_OK;
+}
+
+int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
+    if (!ctx) return PT_ERR_INVALID;
+    DeviceGuard guard(ctx->device);
+    int st = Validate(ctx, d);
+    if (st != PT_OK) return st;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    FreeScene(ctx);
+    st = EnsureScratch(ctx);
+    if (st != PT_OK) return st;
+
+    // which mesh (index range) does each BLAS describe?
+    std::vector<int> blas_owner(d->blas_count, -1);
+    for (uint32_t i = 0; i < d->geometry_count; ++i) {
+        const pt_geometry_instance &g = d->geometries[i];
+        int &owner = blas_owner[g.blas_index];
+        if (owner < 0) {
+            owner = int(i);
+        } else {
+            const pt_geometry_instance &o = d->geometries[owner];
+            if (o.first_index != g.first_index || o.index_count != g.index_count)
+                return Fail(ctx, PT_ERR_INVALID, "instances %d and %u share BLAS %d but not the mesh range", owner, i, g.blas_index);
+        }
+    }
+
+    // ---- triangle records in leaf order
+    std::vector<DTri> tris(d->tri_index_count);
+    std::memset(tris.data(), 0, tris.size() * sizeof(DTri));
+    for (uint32_t b = 0; b < d->blas_count; ++b) {
+        const pt_blas &blas = d->blases[b];
+        if (blas.node_count == 0 || blas_owner[b] < 0) continue;
+        const pt_geometry_instance &g = d->geometries[blas_owner[b]];
+        for (uint32_t j = 0; j < blas.index_count; ++j) {
+            const uint32_t tri = d->tri_indices[blas.first_index + j];
+            if (tri >= g.index_count / 3) return Fail(ctx, PT_ERR_INVALID, "BLAS %u: triangle index %u out of range", b, tri);
+            const float *p[3];
+            for (int k = 0; k < 3; ++k) p[k] = d->positions + 3 * size_t(d->indices[g.first_index + tri * 3 + k]);
+            DTri &r = tris[blas.first_index + j];
+            r.a = make_float4(p[0][0], p[0][1], p[0][2], p[1][0]);
+            r.b = make_float4(p[1][1], p[1][2], p[2][0], p[2][1]);
+            r.c = make_float4(p[2][2], __builtin_bit_cast(float, tri), 0.0f, 0.0f);
+        }
+    }
+
+    // ---- interior nodes: TLAS first, then every BLAS
+    std::vector<DNode> nodes;
+    std::vector<uint2> big_leaves;
+    std::vector<uint32_t> tlas_map(d->tlas_node_count, kNoRef);
+    for (uint32_t i = 0; i < d->tlas_node_count; ++i)
+        if (d->tlas_nodes[i].left_right != 0) {
+            tlas_map[i] = uint32_t(nodes.size());
+            nodes.emplace_back();
+        }
+    auto tlas_ref = [&](uint32_t i) -> uint32_t {
+        const pt_tlas_node &n = d->tlas_nodes[i];
+        return n.left_right == 0 ? (kLeafBit | n.instance) : tlas_map[i];
+    };
+    for (uint32_t i = 0; i < d->tlas_node_count; ++i) {
+        const pt_tlas_node &n = d->tlas_nodes[i];
+        if (n.left_right == 0) continue;
+        const uint32_t l = n.left_right & 0xFFFFu, r = n.left_right >> 16;
+        DNode &dn = nodes[tlas_map[i]];
+        std::memset(&dn, 0, sizeof(dn));
+        SetNodeChild(dn, 0, d->tlas_nodes[l].min, d->tlas_nodes[l].max, tlas_ref(l));
+        SetNodeChild(dn, 1, d->tlas_nodes[r].min, d->tlas_nodes[r].max, tlas_ref(r));
+    }
+    const uint32_t root_ref = tlas_ref(0);
+
+    std::vector<uint32_t> blas_root(d->blas_count, kNoRef);
+    std::vector<uint32_t> node_map(d->blas_node_count, kNoRef);
+    for (uint32_t b = 0; b < d->blas_count; ++b) {
+        const pt_blas &blas = d->blases[b];
+        if (blas.node_count == 0) continue;
+        for (uint32_t k = blas.first_node; k < blas.first_node + blas.node_count; ++k)
+            if (d->blas_nodes[k].primitive_count == 0) {
+                node_map[k] = uint32_t(nodes.size());
+                nodes.emplace_back();
+            }
+        auto ref_of = [&](uint32_t k) -> uint32_t {
+            const pt_bvh_node &n = d->blas_nodes[k];
+            if (n.primitive_count > 0) return EncodeLeaf(blas.first_index + n.first_primitive, n.primitive_count, big_leaves);
+            return node_map[k];
+        };
+        for (uint32_t k = blas.first_node; k < blas.first_node + blas.node_count; ++k) {
+            const pt_bvh_node &n = d->blas_nodes[k];
+            if (n.primitive_count > 0) continue;
+            const uint32_t l = n.first_primitive, r = l + 1;
+            DNode &dn = nodes[node_map[k]];
+            std::memset(&dn, 0, sizeof(dn));
+            SetNodeChild(dn, 0, d->blas_nodes[l].min, d->blas_nodes[l].max, ref_of(l));
+            SetNodeChild(dn, 1, d->blas_nodes[r].min, d->blas_nodes[r].max, ref_of(r));
+        }
+        blas_root[b] = ref_of(blas.first_node);
+    }
+    if (nodes.size() >= kNoRef) return Fail(ctx, PT_ERR_LIMIT, "too many BVH nodes");
+
+    // ---- instances
+    std::vector<DInst> insts(d->geometry_count);
+    std::vector<DInstFwd> fwd(d->geometry_count);
+    for (uint32_t i = 0; i < d->geometry_count; ++i) {
+        const pt_geometry_instance &g = d->geometries[i];
+        auto col = [](const float *m, int c, int r) { return m[c * 4 + r]; };
+        const float *I = g.inv_transform, *T = g.transform, *N = g.inv_transpose;
+        DInst &in = insts[i];
+        in.a = make_float4(col(I, 0, 0), col(I, 0, 1), col(I, 0, 2), col(I, 1, 0));
+        in.b = make_float4(col(I, 1, 1), col(I, 1, 2), col(I, 2, 0), col(I, 2, 1));
+        in.c = make_float4(col(I, 2, 2), col(I, 3, 0), col(I, 3, 1), col(I, 3, 2));
+        in.d = make_float4(__builtin_bit_cast(float, blas_root[g.blas_index]), __builtin_bit_cast(float, uint32_t(g.material_id)),
+                           __builtin_bit_cast(float, uint32_t(d->materials[g.material_id].type)), __builtin_bit_cast(float, g.first_index));
+        DInstFwd &f = fwd[i];
+        f.t0 = make_float4(col(T, 0, 0), col(T, 0, 1), col(T, 0, 2), col(T, 1, 0));
+        f.t1 = make_float4(col(T, 1, 1), col(T, 1, 2), col(T, 2, 0), col(T, 2, 1));
+        f.t2 = make_float4(col(T, 2, 2), col(T, 3, 0), col(T, 3, 1), col(T, 3, 2));
+        f.n0 = make_float4(col(N, 0, 0), col(N, 0, 1), col(N, 0, 2), col(N, 1, 0));
+        f.n1 = make_float4(col(N, 1, 1), col(N, 1, 2), col(N, 2, 0), col(N, 2, 1));
+        f.n2 = make_float4(col(N, 2, 2), col(N, 3, 0), col(N, 3, 1), col(N, 3, 2));
+        f.m = make_float4(g.total_area, __builtin_bit_cast(float, uint32_t(g.area_light_id)),
+                          __builtin_bit_cast(float, uint32_t(g.triangle_sampler_index)), __builtin_bit_cast(float, uint32_t(g.material_id)));
+    }
+
+    // ---- materials, textures, images
+    std::vector<DMaterial> mats(d->material_count);
+    for (uint32_t i = 0; i < d->material_count; ++i) {
+        const pt_material &m = d->materials[i];
+        mats[i].type = m.type;
+        mats[i].tex0 = m.tex0;
+        std::memcpy(&mats[i].w1, &m.w1, 4);
+        mats[i].w2 = m.w2;
+    }
+    std::vector<DTex> tex1(d->texture1_count), tex3(d->texture3_count);
+    for (uint32_t i = 0; i < d->texture1_count; ++i) {
+        const pt_texture1 &t = d->textures1[i];
+        DTex &o = tex1[i];
+        std::memset(&o, 0, sizeof(o));
+        o.type = t.type;
+        o.image_id = -1;
+        if (t.type == PT_TEX_CONSTANT) {
+            o.c0[0] = t.u.constant.value;
+        } else if (t.type == PT_TEX_IMAGE) {
+            o.image_id = t.u.image.image_id;
+            o.width = t.u.image.width;
+            o.height = t.u.image.height;
+            std::memcpy(o.scale, t.u.image.scale, 8);
+            std::memcpy(o.offset, t.u.image.offset, 8);
+        } else if (t.type == PT_TEX_CHECKERBOARD) {
+            o.c0[0] = t.u.checkerboard.color0;
+            o.c1[0] = t.u.checkerboard.color1;
+            std::memcpy(o.scale, t.u.checkerboard.scale, 8);
+            std::memcpy(o.offset, t.u.checkerboard.offset, 8);
+        } else {
+            return Fail(ctx, PT_ERR_INVALID, "scalar texture %u: unknown type", i);
+        }
+    }
+    for (uint32_t i = 0; i < d->texture3_count; ++i) {
+        const pt_texture3 &t = d->textures3[i];
+        DTex &o = tex3[i];
+        std::memset(&o, 0, sizeof(o));
+        o.type = t.type;
+        o.image_id = -1;
+        if (t.type == PT_TEX_CONSTANT) {
+            std::memcpy(o.c0, t.u.constant.value, 12);
+        } else if (t.type == PT_TEX_IMAGE) {
+            o.image_id = t.u.image.image_id;
+            o.width = t.u.image.width;
+            o.height = t.u.image.height;
+            std::memcpy(o.scale, t.u.image.scale, 8);
+            std::memcpy(o.offset, t.u.image.offset, 8);
+        } else if (t.type == PT_TEX_CHECKERBOARD) {
+            std::memcpy(o.c0, t.u.checkerboard.color0, 12);
+            std::memcpy(o.c1, t.u.checkerboard.color1, 12);
+            std::memcpy(o.scale, t.u.checkerboard.scale, 8);
+            std::memcpy(o.offset, t.u.checkerboard.offset, 8);
+        } else {
+            return Fail(ctx, PT_ERR_INVALID, "colour texture %u: unknown type", i);
+        }
+    }
+    DScene &S = ctx->scene;
+    std::vector<DImage> img1(d->image1_count), img3(d->image3_count);
+    for (uint32_t i = 0; i < d->image1_count; ++i) {
+        const pt_image &im = d->images1[i];
+        if (!im.data || im.width <= 0 || im.height <= 0 || im.channels != 1) return Fail(ctx, PT_ERR_INVALID, "scalar image %u is malformed", i);
+        const float *dev = nullptr;
+        st = Upload(ctx, ctx->scene_allocs, im.data, size_t(im.width) * im.height, &dev);
+        if (st != PT_OK) return st;
+        img1[i] = DImage{dev, im.width, im.height};
+    }
+    for (uint32_t i = 0; i < d->image3_count; ++i) {
+        const pt_image &im = d->images3[i];
+        if (!im.data || im.width <= 0 || im.height <= 0 || im.channels != 3) return Fail(ctx, PT_ERR_INVALID, "colour image %u is malformed", i);
+        std::vector<float4> rgba(size_t(im.width) * im.height);  // float4 texels as texture.cpp:40-53
+        for (size_t k = 0; k < rgba.size(); ++k) rgba[k] = make_float4(im.data[3 * k], im.data[3 * k + 1], im.data[3 * k + 2], 1.0f);
+        const float4 *dev = nullptr;
+        st = Upload(ctx, ctx->scene_allocs, rgba.data(), rgba.size(), &dev);
+        if (st != PT_OK) return st;
+        img3[i] = DImage{dev, im.width, im.height};
+    }
+
+    // ---- alias tables
+    std::vector<DAlias> tri_samplers(d->triangle_sampler_count);
+    for (uint32_t i = 0; i < d->triangle_sampler_count; ++i) {
+        const pt_alias_table &t = d->triangle_samplers[i];
+        const float *p = nullptr;
+        const uint32_t *a = nullptr;
+        if ((st = Upload(ctx, ctx->scene_allocs, t.probability_table, t.size, &p)) != PT_OK) return st;
+        if ((st = Upload(ctx, ctx->scene_allocs, t.alias_table, t.size, &a)) != PT_OK) return st;
+        tri_samplers[i] = DAlias{p, a, t.size, 0};
+    }
+    S.light_sampler = DAlias{nullptr, nullptr, 0, 0};
+    if (d->light_count > 0) {
+        const float *p = nullptr;
+        const uint32_t *a = nullptr;
+        if ((st = Upload(ctx, ctx->scene_allocs, d->light_sampler->probability_table, d->light_sampler->size, &p)) != PT_OK) return st;
+        if ((st = Upload(ctx, ctx->scene_allocs, d->light_sampler->alias_table, d->light_sampler->size, &a)) != PT_OK) return st;
+        S.light_sampler = DAlias{p, a, d->light_sampler->size, 0};
+    }
+
+#define UP(field, vec)                                                                             \
+    if ((st = Upload(ctx, ctx->scene_allocs, (vec).data(), (vec).size(), &S.field)) != PT_OK) return st
+    UP(nodes, nodes);
+    UP(tris, tris);
+    UP(insts, insts);
+    UP(fwd, fwd);
+    UP(big_leaves, big_leaves);
+    UP(materials, mats);
+    UP(tex1, tex1);
+    UP(tex3, tex3);
+    UP(images1, img1);
+    UP(images3, img3);
+    UP(tri_samplers, tri_samplers);
+#undef UP
+    if ((st = Upload(ctx, ctx->scene_allocs, d->indices, d->index_count, &S.indices)) != PT_OK) return st;
+    if ((st = Upload(ctx, ctx->scene_allocs, d->positions, size_t(d->vertex_count) * 3, &S.positions)) != PT_OK) return st;
+    if ((st = Upload(ctx, ctx->scene_allocs, d->normals, size_t(d->vertex_count) * 3, &S.normals)) != PT_OK) return st;
+    if ((st = Upload(ctx, ctx->scene_allocs, d->uvs, size_t(d->vertex_count) * 2, &S.uvs)) != PT_OK) return st;
+    if ((st = Upload(ctx, ctx->scene_allocs, d->lights, d->light_count, &S.lights)) != PT_OK) return st;
+    S.tex1_count = d->texture1_count;
+    S.tex3_count = d->texture3_count;
+    S.image1_count = d->image1_count;
+    S.image3_count = d->image3_count;
+    S.light_count = d->light_count;
+    S.material_count = d->material_count;
+    S.geometry_count = d->geometry_count;
+    S.root_ref = root_ref;
+    for (int a = 0; a < 3; ++a) {
+        S.root_min[a] = d->tlas_nodes[0].min[a];
+        S.root_max[a] = d->tlas_nodes[0].max[a];
+    }
+    S.max_depth = d->max_depth;
+    S.total_light_power = d->total_light_power;
+    FillCamera(S.camera, d->camera);
+    ctx->scene_ready = true;
+    return PT_OK;
+}
+
+// ------------------------------------------------------------------ integrator
+int pt_integrator_destroy(pt_ctx *ctx) {
+    if (!ctx) return PT_ERR_INVALID;
+    DeviceGuard guard(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    FreeAll(ctx->path_allocs);
+    ctx->film = nullptr;
+    ctx->counters = nullptr;
+    ctx->counters_capacity = 0;
+    std::memset(&ctx->paths, 0, sizeof(ctx->paths));
+    ctx->integrator_ready = false;
+    ctx->width = ctx->height = 0;
+    return PT_OK;
+}
+
+int pt_integrator_init(pt_ctx *ctx, int width, int height) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (width <= 0 || height <= 0) return Fail(ctx, PT_ERR_INVALID, "resolution must be positive");
+    if (uint64_t(width) * uint64_t(height) > (1ull << 28)) return Fail(ctx, PT_ERR_LIMIT, "more than 2^28 pixels");
+    DeviceGuard guard(ctx->device);
+    pt_integrator_destroy(ctx);
+    int st = EnsureScratch(ctx);
+    if (st != PT_OK) return st;
+    const uint32_t tiles = uint32_t((width + 7) / 8) * uint32_t((height + 7) / 8);
+    const size_t cap = size_t(tiles) * 64;
+    PathState &P = ctx->paths;
+    P.capacity = uint32_t(cap);
+#define AL(field) if ((st = Alloc(ctx, ctx->path_allocs, cap, &P.field)) != PT_OK) return st
+    AL(ray_o); AL(ray_d); AL(thr); AL(accum); AL(last_pos); AL(rng); AL(hit); AL(hit_inst); AL(sh_o); AL(sh_d); AL(sh_c);
+    AL(ext_q[0]); AL(ext_q[1]);
+    for (int k = 0; k < kNumClasses; ++k) AL(class_q[k]);
+#undef AL
+    if ((st = Alloc(ctx, ctx->path_allocs, size_t(width) * height * 3, &ctx->film)) != PT_OK) return st;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->film, 0, size_t(width) * height * 3 * sizeof(float), ctx->stream));
+    ctx->width = width;
+    ctx->height = height;
+    ctx->integrator_ready = true;
+    return PT_OK;
+}
+
+int pt_integrator_resize(pt_ctx *ctx, int width, int height) { return pt_integrator_init(ctx, width, height); }
+
+int pt_integrator_reset(pt_ctx *ctx, int width, int height) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->integrator_ready) return Fail(ctx, PT_ERR_STATE, "pt_integrator_reset before pt_integrator_init");
+    if (width != ctx->width || height != ctx->height) return Fail(ctx, PT_ERR_INVALID, "reset resolution differs from the integrator's");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->film, 0, size_t(width) * height * 3 * sizeof(float), ctx->stream));
+    return PT_OK;
+}
+
+static int EnsureCounters(pt_ctx *ctx, uint32_t bounces) {
+    if (ctx->counters_capacity >= bounces + 2) return PT_OK;
+    BounceCounters *c = nullptr;
+    int st = Alloc(ctx, ctx->path_allocs, size_t(bounces) + 2, &c);
+    if (st != PT_OK) return st;
+    ctx->counters = c;
+    ctx->counters_capacity = bounces + 2;
+    return PT_OK;
+}
+
+// Runs generate + `bounces` bounce rounds of iteration `iteration` (no film pass).
+static int RunBounces(pt_ctx *ctx, int width, int height, int iteration, int bounces, bool shade_last) {
+    const DScene &S = ctx->scene;
+    PathState &P = ctx->paths;
+    int st = EnsureCounters(ctx, S.max_depth);
+    if (st != PT_OK) return st;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, size_t(ctx->counters_capacity) * sizeof(BounceCounters), ctx->stream));
+    const uint32_t tiles = P.capacity / 64;
+    {
+        ScopedEvent ev(ctx, EV_GENERATE);
+        hipLaunchKernelGGL(k_generate, dim3(tiles), dim3(kWave), 0, ctx->stream, S, P, ctx->counters, iteration, width, height);
+    }
+    const dim3 grid(ctx->grid_blocks), block(kWave);
+    ctx->last_render_bounces = bounces;
+    for (int b = 0; b < bounces; ++b) {
+        const bool last = (b == bounces - 1);
+        if (last && !shade_last) break;
+        {
+            ScopedEvent ev(ctx, EV_CLOSEST);
+            hipLaunchKernelGGL(k_extend, grid, block, 0, ctx->stream, S, P, ctx->counters, b, ctx->spill, ctx->spill_stride, ctx->dev_stats);
+        }
+        {
+            ScopedEvent ev(ctx, EV_SHADE);
+            hipLaunchKernelGGL(k_shade, grid, block, 0, ctx->stream, S, P, ctx->counters, b);
+        }
+        {
+            ScopedEvent ev(ctx, EV_ANY);
+            hipLaunchKernelGGL(k_shadow, grid, block, 0, ctx->stream, S, P, ctx->counters, b, ctx->spill, ctx->spill_stride, ctx->dev_stats);
+        }
+        // long depth limits: stop launching once the extension queue has drained
+        if ((b & 7) == 7 && b + 1 < bounces) {
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned_word, &ctx->counters[b + 1].ext_count, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (*ctx->pinned_word == 0) {
+                ctx->last_render_bounces = b + 1;
+                break;
+            }
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+int pt_render_async(pt_ctx *ctx, int width, int height, int iteration, uint8_t *rgba_device) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->scene_ready) return Fail(ctx, PT_ERR_STATE, "pt_render before pt_scene_upload");
+    if (!ctx->integrator_ready) return Fail(ctx, PT_ERR_STATE, "pt_render before pt_integrator_init");
+    if (width != ctx->width || height != ctx->height) return Fail(ctx, PT_ERR_INVALID, "render resolution %dx%d differs from the integrator's %dx%d", width, height, ctx->width, ctx->height);
+    if (width != ctx->scene.camera.res_x || height != ctx->scene.camera.res_y)
+        return Fail(ctx, PT_ERR_INVALID, "render resolution differs from the camera's");
+    if (iteration < 0) return Fail(ctx, PT_ERR_INVALID, "iteration must be >= 0");
+    DeviceGuard guard(ctx->device);
+    if (iteration == 0) HIP_TRY(ctx, hipMemsetAsync(ctx->film, 0, size_t(width) * height * 3 * sizeof(float), ctx->stream));  // path_trace.cu:438-439
+    int st = RunBounces(ctx, width, height, iteration, int(ctx->scene.max_depth), true);
+    if (st != PT_OK) return st;
+    {
+        ScopedEvent ev(ctx, EV_FILM);
+        hipLaunchKernelGGL(k_film, dim3(ctx->paths.capacity / 64), dim3(kWave), 0, ctx->stream, ctx->paths, ctx->film, width, height, ctx->dev_stats);
+    }
+    if (rgba_device) {
+        const uint32_t n = uint32_t(width) * uint32_t(height);
+        hipLaunchKernelGGL(k_tonemap, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->film, rgba_device, width, height, iteration + 1);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+int pt_render(pt_ctx *ctx, int width, int height, int iteration, uint8_t *rgba_device) {
+    int st = pt_render_async(ctx, width, height, iteration, rgba_device);
+    if (st != PT_OK) return st;
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // path_trace.cu:481
+    return PT_OK;
+}
+
+int pt_film_download(pt_ctx *ctx, float *rgb_host) {
+    if (!ctx || !rgb_host) return PT_ERR_INVALID;
+    if (!ctx->integrator_ready) return Fail(ctx, PT_ERR_STATE, "no film: integrator not initialised");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, hipMemcpyAsync(rgb_host, ctx->film, size_t(ctx->width) * ctx->height * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_film_copy_to_device(pt_ctx *ctx, float *rgb_device) {
+    if (!ctx || !rgb_device) return PT_ERR_INVALID;
+    if (!ctx->integrator_ready) return Fail(ctx, PT_ERR_STATE, "no film: integrator not initialised");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, hipMemcpyAsync(rgb_device, ctx->film, size_t(ctx->width) * ctx->height * 3 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_film_copy_from_device(pt_ctx *ctx, const float *rgb_device) {
+    if (!ctx || !rgb_device) return PT_ERR_INVALID;
+    if (!ctx->integrator_ready) return Fail(ctx, PT_ERR_STATE, "no film: integrator not initialised");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->film, rgb_device, size_t(ctx->width) * ctx->height * 3 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_tonemap(pt_ctx *ctx, const float *film_device, int width, int height, int iterations, uint8_t *rgba_device) {
+    if (!ctx || !rgba_device) return PT_ERR_INVALID;
+    if (width <= 0 || height <= 0 || iterations <= 0) return Fail(ctx, PT_ERR_INVALID, "pt_tonemap: bad size or iteration count");
+    if (!film_device) {
+        if (!ctx->integrator_ready || width != ctx->width || height != ctx->height) return Fail(ctx, PT_ERR_STATE, "pt_tonemap: no matching film");
+        film_device = ctx->film;
+    }
+    DeviceGuard guard(ctx->device);
+    const uint32_t n = uint32_t(width) * uint32_t(height);
+    hipLaunchKernelGGL(k_tonemap, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, film_device, rgba_device, width, height, iterations);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+// ------------------------------------------------------------------ batch queries
+static int CheckQuery(pt_ctx *ctx, const void *a, const void *b, size_t n) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->scene_ready) return Fail(ctx, PT_ERR_STATE, "ray query before pt_scene_upload");
+    if (n > 0 && (!a || !b)) return Fail(ctx, PT_ERR_INVALID, "ray query: null buffer");
+    if (n >= (1ull << 31)) return Fail(ctx, PT_ERR_LIMIT, "ray query: more than 2^31-1 rays per call");
+    if ((reinterpret_cast<uintptr_t>(a) & 15u) != 0) return Fail(ctx, PT_ERR_INVALID, "ray buffer must be 16-byte aligned");
+    return PT_OK;
+}
+
+int pt_trace_closest(pt_ctx *ctx, const pt_ray *rays, size_t n, pt_hit *hits) {
+    int st = CheckQuery(ctx, rays, hits, n);
+    if (st != PT_OK || n == 0) return st;
+    if ((reinterpret_cast<uintptr_t>(hits) & 15u) != 0) return Fail(ctx, PT_ERR_INVALID, "hit buffer must be 16-byte aligned");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->cursor, 0, sizeof(uint32_t), ctx->stream));
+    const uint32_t blocks = uint32_t(std::min<size_t>(ctx->grid_blocks, (n + kWave - 1) / kWave));
+    {
+        ScopedEvent ev(ctx, EV_CLOSEST);
+        hipLaunchKernelGGL(k_trace_closest<false>, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor,
+                           ctx->spill, ctx->spill_stride, ctx->dev_stats, static_cast<TraceCounters *>(nullptr));
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+int pt_trace_any(pt_ctx *ctx, const pt_ray *rays, size_t n, uint8_t *occluded) {
+    int st = CheckQuery(ctx, rays, occluded, n);
+    if (st != PT_OK || n == 0) return st;
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->cursor, 0, sizeof(uint32_t), ctx->stream));
+    const uint32_t blocks = uint32_t(std::min<size_t>(ctx->grid_blocks, (n + kWave - 1) / kWave));
+    {
+        ScopedEvent ev(ctx, EV_ANY);
+        hipLaunchKernelGGL(k_trace_any, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), occluded, ctx->cursor, ctx->spill,
+                           ctx->spill_stride, ctx->dev_stats);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+int pt_resolve_hits(pt_ctx *ctx, const pt_ray *rays, const pt_hit *hits, size_t n, pt_intersection *out) {
+    int st = CheckQuery(ctx, rays, hits, n);
+    if (st != PT_OK || n == 0) return st;
+    if (!out) return Fail(ctx, PT_ERR_INVALID, "pt_resolve_hits: null output");
+    DeviceGuard guard(ctx->device);
+    hipLaunchKernelGGL(k_resolve_hits, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->scene, rays, hits, uint32_t(n), out);
+    HIP_TRY(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+// Visit counters per ray (interior nodes, TLAS leaves, triangles, BLAS leaves): the counting
+// build of the closest-hit kernel, used to compare traversal work with a CPU traversal.
+int pt_trace_closest_counted(pt_ctx *ctx, const pt_ray *rays, size_t n, pt_hit *hits, uint32_t *counters4) {
+    int st = CheckQuery(ctx, rays, hits, n);
+    if (st != PT_OK || n == 0) return st;
+    if (!counters4) return Fail(ctx, PT_ERR_INVALID, "null counter buffer");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->cursor, 0, sizeof(uint32_t), ctx->stream));
+    const uint32_t blocks = uint32_t(std::min<size_t>(ctx->grid_blocks, (n + kWave - 1) / kWave));
+    hipLaunchKernelGGL(k_trace_closest<true>, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->spill,
+                       ctx->spill_stride, ctx->dev_stats, reinterpret_cast<TraceCounters *>(counters4));
+    HIP_TRY(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+}  // extern "C"
+
+template <typename In, typename Out, typename F>
+static int Staged(pt_ctx *ctx, const In *in, size_t n, Out *out, F &&launch) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (n == 0) return PT_OK;
+    if (!in || !out) return Fail(ctx, PT_ERR_INVALID, "null host buffer");
+    DeviceGuard guard(ctx->device);
+    In *din = nullptr;
+    Out *dout = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&din), n * sizeof(In)));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&dout), n * sizeof(Out));
+    if (e != hipSuccess) {
+        (void)hipFree(din);
+        return Fail(ctx, PT_ERR_DEVICE, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    int st = PT_OK;
+    e = hipMemcpyAsync(din, in, n * sizeof(In), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) st = launch(din, dout);
+    if (e == hipSuccess && st == PT_OK) e = hipMemcpyAsync(out, dout, n * sizeof(Out), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(din);
+    (void)hipFree(dout);
+    if (e != hipSuccess) return Fail(ctx, PT_ERR_DEVICE, "staged query failed: %s", hipGetErrorString(e));
+    return st;
+}
+
+extern "C" {
+
+int pt_trace_closest_host(pt_ctx *ctx, const pt_ray *rays, size_t n, pt_hit *hits) {
+    return Staged(ctx, rays, n, hits, [&](pt_ray *dr, pt_hit *dh) { return pt_trace_closest(ctx, dr, n, dh); });
+}
+int pt_trace_any_host(pt_ctx *ctx, const pt_ray *rays, size_t n, uint8_t *occluded) {
+    return Staged(ctx, rays, n, occluded, [&](pt_ray *dr, uint8_t *d_out) { return pt_trace_any(ctx, dr, n, d_out); });
+}
+int pt_resolve_hits_host(pt_ctx *ctx, const pt_ray *rays, const pt_hit *hits, size_t n, pt_intersection *out) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (n == 0) return PT_OK;
+    if (!rays || !hits || !out) return Fail(ctx, PT_ERR_INVALID, "null host buffer");
+    DeviceGuard guard(ctx->device);
+    pt_hit *dh = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&dh), n * sizeof(pt_hit)));
+    hipError_t e = hipMemcpyAsync(dh, hits, n * sizeof(pt_hit), hipMemcpyHostToDevice, ctx->stream);
+    int st = PT_OK;
+    if (e == hipSuccess)
+        st = Staged(ctx, rays, n, out, [&](pt_ray *dr, pt_intersection *d_out) { return pt_resolve_hits(ctx, dr, dh, n, d_out); });
+    (void)hipFree(dh);
+    if (e != hipSuccess) return Fail(ctx, PT_ERR_DEVICE, "hipMemcpyAsync failed: %s", hipGetErrorString(e));
+    return st;
+}
+
+int pt_generate_incoherent_rays(pt_ctx *ctx, pt_ray *rays_device, size_t n, uint64_t first_index) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->scene_ready) return Fail(ctx, PT_ERR_STATE, "ray generation before pt_scene_upload");
+    if (n == 0) return PT_OK;
+    if (!rays_device || (reinterpret_cast<uintptr_t>(rays_device) & 15u)) return Fail(ctx, PT_ERR_INVALID, "ray buffer must be a 16-byte aligned device pointer");
+    if (n >= (1ull << 31)) return Fail(ctx, PT_ERR_LIMIT, "more than 2^31-1 rays per call");
+    DeviceGuard guard(ctx->device);
+    hipLaunchKernelGGL(k_gen_incoherent, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->scene, rays_device, uint32_t(n), first_index);
+    HIP_TRY(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+int pt_capture_bounce_rays(pt_ctx *ctx, int width, int height, int iteration, int bounce, pt_ray *rays_device, size_t capacity, size_t *count) {
+    if (!ctx || !count) return PT_ERR_INVALID;
+    *count = 0;
+    if (!ctx->scene_ready || !ctx->integrator_ready) return Fail(ctx, PT_ERR_STATE, "capture needs an uploaded scene and an initialised integrator");
+    if (width != ctx->width || height != ctx->height) return Fail(ctx, PT_ERR_INVALID, "capture resolution differs from the integrator's");
+    if (bounce < 0 || uint32_t(bounce) >= ctx->scene.max_depth) return Fail(ctx, PT_ERR_INVALID, "bounce %d outside [0, max_depth)", bounce);
+    if (!rays_device || (reinterpret_cast<uintptr_t>(rays_device) & 15u)) return Fail(ctx, PT_ERR_INVALID, "ray buffer must be a 16-byte aligned device pointer");
+    DeviceGuard guard(ctx->device);
+    int st = RunBounces(ctx, width, height, iteration, bounce + 1, false);
+    if (st != PT_OK) return st;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned_word, &ctx->counters[bounce].ext_count, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t n = std::min<size_t>(*ctx->pinned_word, capacity);
+    if (n > 0) {
+        hipLaunchKernelGGL(k_gather_rays, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->paths, ctx->counters, bounce, rays_device, uint32_t(capacity));
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    *count = n;
+    return PT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,437 @@
+"""Thin Python handles over the C ABI: Context (pt_ctx), HostScene (pth_scene), Integrator.
+
+Mirrors the reference's object model for the hot path: a Scene that owns host arrays and
+uploads them (Scene::UpdateDevice, scene.cpp:52-96) and an Integrator with
+Init/Resize/Reset/Render (kernel/integrators/integrator.h:11-24).  Device buffers are passed
+as integer addresses (e.g. ``tensor.data_ptr()``); nothing here allocates GPU memory itself.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+
+class PtError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[ptamd status {code}] {message}")
+        self.code = code
+
+
+def _host_check(status: int):
+    if status != abi.PT_OK:
+        raise PtError(status, abi.load_library().pth_last_error().decode())
+
+
+def _f3(v):
+    a = np.ascontiguousarray(np.asarray(v, dtype=np.float32).reshape(3))
+    return a
+
+
+# --------------------------------------------------------------------------- host helpers
+def transform_matrix(translate, rotate_deg, scale) -> np.ndarray:
+    """Math::GetTransformMatrix (math/transform.cpp:5-14) -> float32[16], column-major."""
+    lib = abi.load_library()
+    out = np.zeros(16, np.float32)
+    _host_check(lib.pth_transform_matrix(abi.fptr(_f3(translate)), abi.fptr(_f3(rotate_deg)), abi.fptr(_f3(scale)), abi.fptr(out)))
+    return out
+
+
+def matrix_derive(transform: np.ndarray):
+    """glm::inverse and glm::inverseTranspose of a column-major mat4 (scene.cpp:415-417)."""
+    lib = abi.load_library()
+    t = np.ascontiguousarray(transform, np.float32).reshape(16)
+    inv, invt = np.zeros(16, np.float32), np.zeros(16, np.float32)
+    _host_check(lib.pth_matrix_derive(abi.fptr(t), abi.fptr(inv), abi.fptr(invt)))
+    return inv, invt
+
+
+def matrix_mul(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    lib = abi.load_library()
+    out = np.zeros(16, np.float32)
+    _host_check(lib.pth_matrix_mul(abi.fptr(np.ascontiguousarray(a, np.float32).reshape(16)),
+                                   abi.fptr(np.ascontiguousarray(b, np.float32).reshape(16)), abi.fptr(out)))
+    return out
+
+
+def gltf_local_matrix(translation, rotation_xyzw, scale, matrix) -> np.ndarray:
+    lib = abi.load_library()
+    out = np.zeros(16, np.float32)
+    q = np.ascontiguousarray(np.asarray(rotation_xyzw, np.float32).reshape(4))
+    m = np.ascontiguousarray(np.asarray(matrix, np.float32).reshape(16))
+    _host_check(lib.pth_gltf_local_matrix(abi.fptr(_f3(translation)), abi.fptr(q), abi.fptr(_f3(scale)), abi.fptr(m), abi.fptr(out)))
+    return out
+
+
+def alias_build(weights: np.ndarray):
+    """DiscreteSampler1D::UpdateWeights (discrete_sampler.cpp:14-76) -> (probability, alias)."""
+    lib = abi.load_library()
+    w = np.ascontiguousarray(weights, np.float32)
+    prob = np.zeros(len(w), np.float32)
+    alias = np.zeros(len(w), np.uint32)
+    _host_check(lib.pth_alias_build(abi.fptr(w), len(w), abi.fptr(prob), abi.uptr(alias)))
+    return prob, alias
+
+
+def camera_make(eye, look_at, up, fovy_deg: float, width: int, height: int) -> abi.Camera:
+    """Camera::Update + UpdateDevice (camera.cpp:6-51)."""
+    lib = abi.load_library()
+    cam = abi.Camera()
+    _host_check(lib.pth_camera_make(abi.fptr(_f3(eye)), abi.fptr(_f3(look_at)), abi.fptr(_f3(up)), float(fovy_deg), width, height, C.byref(cam)))
+    return cam
+
+
+def bvh_build(positions: np.ndarray, indices: np.ndarray, geometries: np.ndarray):
+    """TLAS::Build (bvh.cpp:206-332) -> dict of reference-layout arrays."""
+    lib = abi.load_library()
+    pos = np.ascontiguousarray(positions, np.float32)
+    idx = np.ascontiguousarray(indices, np.uint32)
+    geo = np.ascontiguousarray(geometries, abi.GEOMETRY)
+    h = C.c_void_p()
+    _host_check(lib.pth_bvh_build(abi.fptr(pos.reshape(-1)), abi.uptr(idx), abi.vptr(geo), len(geo), C.byref(h)))
+    try:
+        n = [C.c_uint32() for _ in range(4)]
+        _host_check(lib.pth_bvh_sizes(h, *[C.byref(x) for x in n]))
+        out = {"tlas_nodes": np.zeros(n[0].value, abi.TLAS_NODE), "blases": np.zeros(n[1].value, abi.BLAS),
+               "blas_nodes": np.zeros(n[2].value, abi.BVH_NODE), "tri_indices": np.zeros(n[3].value, np.uint32)}
+        _host_check(lib.pth_bvh_get(h, abi.vptr(out["tlas_nodes"]), abi.vptr(out["blases"]), abi.vptr(out["blas_nodes"]),
+                                    abi.vptr(out["tri_indices"])))
+        return out
+    finally:
+        lib.pth_bvh_free(h)
+
+
+def save_png(path: str, rgba: np.ndarray):
+    lib = abi.load_library()
+    a = np.ascontiguousarray(rgba, np.uint8)
+    h, w = a.shape[0], a.shape[1]
+    _host_check(lib.pth_save_png(path.encode(), abi.vptr(a), w, h))
+
+
+def save_hdr(path: str, film: np.ndarray, iterations: int):
+    lib = abi.load_library()
+    a = np.ascontiguousarray(film, np.float32)
+    h, w = a.shape[0], a.shape[1]
+    _host_check(lib.pth_save_hdr(path.encode(), abi.vptr(a), w, h, int(iterations)))
+
+
+# --------------------------------------------------------------------------- HostScene
+class HostScene:
+    """pth_scene: the host-side Scene of the facade (scene.h:23-186), filled programmatically."""
+
+    def __init__(self):
+        self._lib = abi.load_library()
+        self._h = C.c_void_p()
+        _host_check(self._lib.pth_scene_create(C.byref(self._h)))
+        self.width = self.height = 0
+        self.max_depth, self.max_iterations = 4, 1000
+
+    def close(self):
+        if self._h:
+            self._lib.pth_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_integrator(self, max_depth: int, max_iterations: int):
+        _host_check(self._lib.pth_scene_set_integrator(self._h, int(max_depth), int(max_iterations)))
+        self.max_depth, self.max_iterations = int(max_depth), int(max_iterations)
+
+    def set_camera(self, eye, look_at, up, fovy_deg, width, height):
+        _host_check(self._lib.pth_scene_set_camera(self._h, abi.fptr(_f3(eye)), abi.fptr(_f3(look_at)), abi.fptr(_f3(up)),
+                                                   float(fovy_deg), int(width), int(height)))
+        self.width, self.height = int(width), int(height)
+
+    def add_mesh(self, positions, normals, uvs, indices) -> int:
+        p = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        n = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(uvs, np.float32).reshape(-1, 2)
+        i = np.ascontiguousarray(indices, np.uint32).reshape(-1)
+        assert len(p) == len(n) == len(t)
+        first = C.c_uint32()
+        _host_check(self._lib.pth_scene_add_mesh(self._h, abi.fptr(p.reshape(-1)), abi.fptr(n.reshape(-1)), abi.fptr(t.reshape(-1)),
+                                                 len(p), abi.uptr(i), len(i), C.byref(first)))
+        return first.value
+
+    def add_material(self, mtype: int, tex0: int = 0, w1=0, w2: int = 0) -> int:
+        m = abi.Material()
+        m.type = mtype
+        m.tex0 = int(tex0)
+        m.w1 = int(np.float32(w1).view(np.uint32)) if isinstance(w1, (float, np.floating)) else int(np.int32(w1).view(np.uint32))
+        m.w2 = int(w2)
+        out = C.c_int()
+        _host_check(self._lib.pth_scene_add_material(self._h, C.byref(m), C.byref(out)))
+        return out.value
+
+    def add_constant_texture3(self, rgb) -> int:
+        t = abi.Texture3()
+        t.type = abi.PT_TEX_CONSTANT
+        for k in range(3):
+            t.u.constant[k] = float(rgb[k])
+        out = C.c_int()
+        _host_check(self._lib.pth_scene_add_texture3(self._h, C.byref(t), C.byref(out)))
+        return out.value
+
+    def add_constant_texture1(self, value: float) -> int:
+        t = abi.Texture1()
+        t.type = abi.PT_TEX_CONSTANT
+        t.u.constant = float(value)
+        out = C.c_int()
+        _host_check(self._lib.pth_scene_add_texture1(self._h, C.byref(t), C.byref(out)))
+        return out.value
+
+    def add_checker_texture3(self, c0, c1, scale=(1.0, 1.0), offset=(0.0, 0.0)) -> int:
+        t = abi.Texture3()
+        t.type = abi.PT_TEX_CHECKERBOARD
+        for k in range(3):
+            t.u.checkerboard.color0[k] = float(c0[k])
+            t.u.checkerboard.color1[k] = float(c1[k])
+        for k in range(2):
+            t.u.checkerboard.scale[k] = float(scale[k])
+            t.u.checkerboard.offset[k] = float(offset[k])
+        out = C.c_int()
+        _host_check(self._lib.pth_scene_add_texture3(self._h, C.byref(t), C.byref(out)))
+        return out.value
+
+    def add_image(self, texels: np.ndarray, srgb: bool = False) -> int:
+        a = np.ascontiguousarray(texels, np.float32)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        h, w, ch = a.shape
+        out = C.c_int()
+        _host_check(self._lib.pth_scene_add_image(self._h, abi.fptr(a.reshape(-1)), w, h, ch, int(srgb), C.byref(out)))
+        return out.value
+
+    def add_image_texture(self, image_id: int, width: int, height: int, channels: int, scale=(1.0, 1.0), offset=(0.0, 0.0)) -> int:
+        t = abi.Texture1() if channels == 1 else abi.Texture3()
+        t.type = abi.PT_TEX_IMAGE
+        t.u.image.width, t.u.image.height, t.u.image.image_id = int(width), int(height), int(image_id)
+        for k in range(2):
+            t.u.image.scale[k] = float(scale[k])
+            t.u.image.offset[k] = float(offset[k])
+        out = C.c_int()
+        fn = self._lib.pth_scene_add_texture1 if channels == 1 else self._lib.pth_scene_add_texture3
+        _host_check(fn(self._h, C.byref(t), C.byref(out)))
+        return out.value
+
+    def new_blas_index(self) -> int:
+        out = C.c_int()
+        _host_check(self._lib.pth_scene_new_blas_index(self._h, C.byref(out)))
+        return out.value
+
+    def add_instance(self, first_index: int, index_count: int, vertex_count: int, material_id: int, transform, blas_index: int) -> int:
+        t = np.ascontiguousarray(transform, np.float32).reshape(16)
+        out = C.c_int()
+        _host_check(self._lib.pth_scene_add_instance(self._h, first_index, index_count, vertex_count, material_id, abi.fptr(t), blas_index, C.byref(out)))
+        return out.value
+
+    def finalize(self):
+        _host_check(self._lib.pth_scene_finalize(self._h))
+
+    def desc(self) -> abi.SceneDesc:
+        """Host-pointer scene description (valid while this object is alive and unchanged)."""
+        d = abi.SceneDesc()
+        _host_check(self._lib.pth_scene_get_desc(self._h, C.byref(d)))
+        return d
+
+    def arrays(self) -> dict:
+        """Copies of the reference-layout arrays (for parity checks against the oracle)."""
+        d = self.desc()
+
+        def view(ptr, count, dtype):
+            if not count:
+                return np.zeros(0, dtype)
+            addr = ptr if isinstance(ptr, int) else C.cast(ptr, C.c_void_p).value
+            buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(addr)
+            return np.frombuffer(buf, dtype=dtype, count=count).copy()
+
+        return {
+            "positions": view(d.positions, d.vertex_count * 3, np.float32).reshape(-1, 3),
+            "normals": view(d.normals, d.vertex_count * 3, np.float32).reshape(-1, 3),
+            "uvs": view(d.uvs, d.vertex_count * 2, np.float32).reshape(-1, 2),
+            "indices": view(d.indices, d.index_count, np.uint32),
+            "geometries": view(d.geometries, d.geometry_count, abi.GEOMETRY),
+            "tlas_nodes": view(d.tlas_nodes, d.tlas_node_count, abi.TLAS_NODE),
+            "blases": view(d.blases, d.blas_count, abi.BLAS),
+            "blas_nodes": view(d.blas_nodes, d.blas_node_count, abi.BVH_NODE),
+            "tri_indices": view(d.tri_indices, d.tri_index_count, np.uint32),
+            "materials": view(d.materials, d.material_count, abi.MATERIAL),
+            "lights": view(d.lights, d.light_count, abi.AREA_LIGHT),
+            "total_light_power": float(d.total_light_power),
+        }
+
+    def update_device(self, ctx: "Context"):
+        _host_check(self._lib.pth_scene_update_device(self._h, ctx.handle))
+
+
+# --------------------------------------------------------------------------- Context
+class Context:
+    """pt_ctx: one GPU, one stream, the uploaded scene and the integrator state."""
+
+    def __init__(self, device: int = 0):
+        self._lib = abi.load_library()
+        self._h = C.c_void_p()
+        st = self._lib.pt_ctx_create(int(device), C.byref(self._h))
+        if st != abi.PT_OK:
+            raise PtError(st, self._lib.pt_last_error(None).decode())
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            self._lib.pt_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def _check(self, status: int):
+        if status != abi.PT_OK:
+            raise PtError(status, self._lib.pt_last_error(self._h).decode())
+
+    def upload(self, desc: abi.SceneDesc):
+        self._check(self._lib.pt_scene_upload(self._h, C.byref(desc)))
+
+    def camera_update(self, cam: abi.Camera):
+        self._check(self._lib.pt_camera_update(self._h, C.byref(cam)))
+
+    def scene_free(self):
+        self._check(self._lib.pt_scene_free(self._h))
+
+    def set_stream(self, stream_ptr: int):
+        self._check(self._lib.pt_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._check(self._lib.pt_synchronize(self._h))
+
+    def set_profiling(self, on: bool):
+        self._check(self._lib.pt_set_profiling(self._h, int(on)))
+
+    def stats(self) -> abi.Stats:
+        s = abi.Stats()
+        self._check(self._lib.pt_get_stats(self._h, C.byref(s)))
+        return s
+
+    def reset_stats(self):
+        self._check(self._lib.pt_reset_stats(self._h))
+
+    # integrator
+    def integrator_init(self, w, h):
+        self._check(self._lib.pt_integrator_init(self._h, w, h))
+
+    def integrator_resize(self, w, h):
+        self._check(self._lib.pt_integrator_resize(self._h, w, h))
+
+    def integrator_reset(self, w, h):
+        self._check(self._lib.pt_integrator_reset(self._h, w, h))
+
+    def integrator_destroy(self):
+        self._check(self._lib.pt_integrator_destroy(self._h))
+
+    def render(self, w, h, iteration, rgba_device_ptr: int = 0, sync: bool = True):
+        fn = self._lib.pt_render if sync else self._lib.pt_render_async
+        self._check(fn(self._h, w, h, iteration, C.c_void_p(rgba_device_ptr)))
+
+    def film_download(self, w, h) -> np.ndarray:
+        out = np.zeros((h, w, 3), np.float32)
+        self._check(self._lib.pt_film_download(self._h, abi.vptr(out)))
+        return out
+
+    def film_copy_to_device(self, ptr: int):
+        self._check(self._lib.pt_film_copy_to_device(self._h, C.c_void_p(ptr)))
+
+    def film_copy_from_device(self, ptr: int):
+        self._check(self._lib.pt_film_copy_from_device(self._h, C.c_void_p(ptr)))
+
+    def tonemap(self, film_ptr: int, w, h, iterations, rgba_ptr: int):
+        self._check(self._lib.pt_tonemap(self._h, C.c_void_p(film_ptr), w, h, iterations, C.c_void_p(rgba_ptr)))
+
+    # batch queries on device pointers
+    def trace_closest(self, rays_ptr: int, n: int, hits_ptr: int):
+        self._check(self._lib.pt_trace_closest(self._h, C.c_void_p(rays_ptr), n, C.c_void_p(hits_ptr)))
+
+    def trace_any(self, rays_ptr: int, n: int, occluded_ptr: int):
+        self._check(self._lib.pt_trace_any(self._h, C.c_void_p(rays_ptr), n, C.c_void_p(occluded_ptr)))
+
+    def trace_closest_counted(self, rays_ptr: int, n: int, hits_ptr: int, counters_ptr: int):
+        self._check(self._lib.pt_trace_closest_counted(self._h, C.c_void_p(rays_ptr), n, C.c_void_p(hits_ptr), C.c_void_p(counters_ptr)))
+
+    def resolve_hits(self, rays_ptr: int, hits_ptr: int, n: int, out_ptr: int):
+        self._check(self._lib.pt_resolve_hits(self._h, C.c_void_p(rays_ptr), C.c_void_p(hits_ptr), n, C.c_void_p(out_ptr)))
+
+    def generate_incoherent_rays(self, rays_ptr: int, n: int, first_index: int = 0):
+        self._check(self._lib.pt_generate_incoherent_rays(self._h, C.c_void_p(rays_ptr), n, first_index))
+
+    def capture_bounce_rays(self, w, h, iteration, bounce, rays_ptr: int, capacity: int) -> int:
+        cnt = C.c_size_t()
+        self._check(self._lib.pt_capture_bounce_rays(self._h, w, h, iteration, bounce, C.c_void_p(rays_ptr), capacity, C.byref(cnt)))
+        return cnt.value
+
+    # host-array conveniences
+    def trace_closest_host(self, rays: np.ndarray) -> np.ndarray:
+        r = np.ascontiguousarray(rays, abi.RAY)
+        hits = np.zeros(len(r), abi.HIT)
+        self._check(self._lib.pt_trace_closest_host(self._h, abi.vptr(r), len(r), abi.vptr(hits)))
+        return hits
+
+    def trace_any_host(self, rays: np.ndarray) -> np.ndarray:
+        r = np.ascontiguousarray(rays, abi.RAY)
+        occ = np.zeros(len(r), np.uint8)
+        self._check(self._lib.pt_trace_any_host(self._h, abi.vptr(r), len(r), abi.vptr(occ)))
+        return occ
+
+    def resolve_hits_host(self, rays: np.ndarray, hits: np.ndarray) -> np.ndarray:
+        r = np.ascontiguousarray(rays, abi.RAY)
+        h = np.ascontiguousarray(hits, abi.HIT)
+        out = np.zeros(len(r), abi.INTERSECTION)
+        self._check(self._lib.pt_resolve_hits_host(self._h, abi.vptr(r), abi.vptr(h), len(r), abi.vptr(out)))
+        return out
+
+
+class PathIntegrator:
+    """PathIntegrator (kernel/integrators/path_trace.h:82-116) through the host facade."""
+
+    def __init__(self, ctx: Context):
+        self._lib = abi.load_library()
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        _host_check(self._lib.pth_integrator_create(ctx.handle, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self._lib.pth_integrator_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def init(self, w, h):
+        _host_check(self._lib.pth_integrator_init(self._h, w, h))
+
+    def resize(self, w, h):
+        _host_check(self._lib.pth_integrator_resize(self._h, w, h))
+
+    def reset(self, w, h):
+        _host_check(self._lib.pth_integrator_reset(self._h, w, h))
+
+    def render(self, w, h, scene: HostScene, rgba_device_ptr: int, iteration: int):
+        _host_check(self._lib.pth_integrator_render(self._h, w, h, scene.handle, C.c_void_p(rgba_device_ptr), iteration))

@@ -1,0 +1,336 @@
+/*
+ * ptamd.h - C ABI of the MI355X ray-scene hot path (libptamd.so).
+ *
+ * This is the boundary a maintainer of the CUDA path tracer binds in place of
+ * its CUDA integrator: the scene is handed over as HOST arrays laid out exactly
+ * as the reference builds them (its BVHNode / TLASNode / GeometryInstance /
+ * Material / Texture<T> PODs), the library re-packs them for gfx950 and owns
+ * all device memory.  Every entry point returns an int status (PT_OK == 0);
+ * no exception crosses the boundary and no glm / torch type appears in a
+ * signature.  Matrices are float[16], column-major (glm::mat4 memory order).
+ *
+ * Citations are file:line in the reference tree (src/...).
+ */
+#ifndef PTAMD_H
+#define PTAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status */
+enum {
+    PT_OK = 0,
+    PT_ERR_INVALID = 1,  /* bad argument / inconsistent scene description   */
+    PT_ERR_DEVICE = 2,   /* a HIP call failed (message in pt_last_error)     */
+    PT_ERR_STATE = 3,    /* call order violated (e.g. render before upload)  */
+    PT_ERR_LIMIT = 4     /* a documented size limit was exceeded             */
+};
+
+/* --------------------------------------------- reference-layout scene PODs */
+
+/* BVHNode, kernel/device_types.h:132-144 (32 B). primitive_count > 0 => leaf,
+ * else first_primitive is the left child and the right child is left+1.      */
+typedef struct pt_bvh_node {
+    float min[3], max[3];
+    uint32_t first_primitive, primitive_count;
+} pt_bvh_node;
+
+/* TLASNode, kernel/device_types.h:146-155 (32 B). left_right == 0 => leaf;
+ * low 16 bits = left child, high 16 bits = right child.                       */
+typedef struct pt_tlas_node {
+    float min[3], max[3];
+    uint32_t instance, left_right;
+} pt_tlas_node;
+
+/* DeviceBLAS, kernel/device_types.h:157-163 (16 B). */
+typedef struct pt_blas {
+    uint32_t first_node, node_count, first_index, index_count;
+} pt_blas;
+
+/* GeometryInstance + TriangleMesh, kernel/device_types.h:181-204 (224 B). */
+typedef struct pt_geometry_instance {
+    int32_t material_id;
+    uint32_t first_index, index_count, vertex_count; /* TriangleMesh */
+    float transform[16];     /* object -> world               */
+    float inv_transform[16]; /* world  -> object              */
+    float inv_transpose[16]; /* covectors object -> world     */
+    int32_t blas_index;
+    float total_area;
+    int32_t triangle_sampler_index;
+    int32_t area_light_id;
+} pt_geometry_instance;
+
+/* Material::Type, kernel/device_types.h:62-72. */
+enum {
+    PT_MAT_LAMBERTIAN = 0,
+    PT_MAT_DIELECTRIC = 1,
+    PT_MAT_MIRROR = 2,
+    PT_MAT_METALLIC_ROUGHNESS = 3,
+    PT_MAT_EMISSIVE = 4
+};
+
+/* Material, kernel/device_types.h:62-82 (16 B tagged union).
+ *   emissive:            tex0 = color_texture,  w1.f = emittance
+ *   dielectric:          tex0 = albedo_texture, w1.f = ior
+ *   lambertian / mirror: tex0 = albedo_texture
+ *   metallic_roughness:  tex0 = albedo, w1.i = metallic_texture, w2 = roughness */
+typedef struct pt_material {
+    uint8_t type;
+    uint8_t _pad[3];
+    int32_t tex0;
+    union { float f; int32_t i; } w1;
+    int32_t w2;
+} pt_material;
+
+/* TextureType, kernel/device_types.h:227-231. */
+enum { PT_TEX_CONSTANT = 0, PT_TEX_IMAGE = 1, PT_TEX_CHECKERBOARD = 2 };
+
+/* Texture<float>, kernel/device_types.h:208-242 (32 B). */
+typedef struct pt_texture1 {
+    uint8_t type;
+    uint8_t _pad[3];
+    union {
+        struct { float value; } constant;
+        struct { int32_t width, height; float scale[2], offset[2]; int32_t image_id; } image;
+        struct { float color0, color1; float scale[2], offset[2]; } checkerboard;
+    } u;
+} pt_texture1;
+
+/* Texture<glm::vec3>, kernel/device_types.h:208-242 (44 B). */
+typedef struct pt_texture3 {
+    uint8_t type;
+    uint8_t _pad[3];
+    union {
+        struct { float value[3]; } constant;
+        struct { int32_t width, height; float scale[2], offset[2]; int32_t image_id; } image;
+        struct { float color0[3], color1[3]; float scale[2], offset[2]; } checkerboard;
+    } u;
+} pt_texture3;
+
+/* A decoded host image as the reference keeps it before upload
+ * (Image<float> / Image<glm::vec3>, texture.cpp:9-74): tightly packed fp32,
+ * row-major, channels == 1 or 3.                                            */
+typedef struct pt_image {
+    const float *data;
+    int32_t width, height, channels;
+    int32_t srgb; /* ColorSpace::sRGB tag; carried, not applied to fp32 texels */
+} pt_image;
+
+/* DeviceDiscreteSampler1D, kernel/device_types.h:122-127 (host pointers here). */
+typedef struct pt_alias_table {
+    const uint32_t *alias_table;
+    const float *probability_table;
+    uint32_t size;
+    uint32_t _pad;
+} pt_alias_table;
+
+/* AreaLight, kernel/device_types.h:260-263. */
+typedef struct pt_area_light {
+    float power;
+    int32_t geometry_instance_index;
+} pt_area_light;
+
+/* DeviceCamera, kernel/device_types.h:102-118 (without the dead film pointer). */
+typedef struct pt_camera {
+    int32_t resolution[2];
+    float position[3];
+    float front[3];
+    float up[3];
+    float right[3];
+    float near_plane, far_plane;
+    float focal_length;
+    float fovy;
+    float pixel_length[2];
+} pt_camera;
+
+/* DeviceScene, kernel/device_scene.h:5-35, with DeviceTLAS
+ * (kernel/device_types.h:165-177) and DeviceTexturePool (:244-256) inlined.
+ * All pointers are HOST pointers and are only read during pt_scene_upload.   */
+typedef struct pt_scene_desc {
+    uint32_t max_depth;
+    uint32_t vertex_count;
+    const float *positions; /* vertex_count * 3 */
+    const float *normals;   /* vertex_count * 3 */
+    const float *uvs;       /* vertex_count * 2 */
+    const uint32_t *indices;
+    uint32_t index_count;
+    uint32_t geometry_count;
+    const pt_geometry_instance *geometries;
+    const pt_alias_table *triangle_samplers;
+    uint32_t triangle_sampler_count;
+    uint32_t tlas_node_count;
+    const pt_tlas_node *tlas_nodes;
+    const pt_blas *blases;
+    uint32_t blas_count;
+    uint32_t blas_node_count;
+    const pt_bvh_node *blas_nodes;
+    const uint32_t *tri_indices;
+    uint32_t tri_index_count;
+    uint32_t material_count;
+    const pt_material *materials;
+    const pt_area_light *lights;
+    uint32_t light_count;
+    float total_light_power;
+    const pt_alias_table *light_sampler; /* may be NULL when light_count == 0 */
+    const pt_texture1 *textures1;
+    const pt_texture3 *textures3;
+    uint32_t texture1_count, texture3_count;
+    const pt_image *images1;
+    const pt_image *images3;
+    uint32_t image1_count, image3_count;
+    pt_camera camera;
+} pt_scene_desc;
+
+/* ------------------------------------------------------------- ray queries */
+
+/* One ray, 32 B = two 16-B words. tmin is reserved (the reference uses a fixed
+ * 1e-9 lower bound, math/intersection.h:63) and must be 0. tmax is the
+ * t_max argument of IntersectScene (kernel/intersection.h:155).              */
+typedef struct pt_ray {
+    float origin[3];
+    float tmin;
+    float direction[3];
+    float tmax;
+} pt_ray;
+
+/* Closest-hit record, 32 B. prim = triangle index inside the instance's mesh
+ * (tri_indices value), inst = GeometryInstance index (Intersection::geometry_id),
+ * u,v = barycentrics of vertices 1 and 2. Miss: t = -1, prim = inst = -1.     */
+typedef struct pt_hit {
+    float t, u, v;
+    int32_t prim;
+    int32_t inst;
+    int32_t material_id;
+    uint32_t _pad[2];
+} pt_hit;
+
+/* Intersection, kernel/intersection.h:10-17 (44 B). */
+typedef struct pt_intersection {
+    float time;
+    float pos[3];
+    float normal[3];
+    float uv[2];
+    int32_t material_id;
+    int32_t geometry_id;
+} pt_intersection;
+
+/* Counters of the last pt_render / pt_trace_* call plus accumulated kernel
+ * timings (valid when profiling was switched on with pt_set_profiling).       */
+#define PT_MAX_TRACKED_BOUNCES 16
+typedef struct pt_stats {
+    uint64_t closest_rays;   /* extension rays traced by the last pt_render   */
+    uint64_t shadow_rays;    /* any-hit rays traced by the last pt_render     */
+    uint64_t paths;          /* camera paths started                          */
+    uint32_t bounces_run;    /* bounce iterations that had work               */
+    uint32_t stack_spills;   /* traversal-stack entries that left LDS         */
+    uint32_t stack_drops;    /* pushes dropped at depth 64 (utils/stack.h:8-11)*/
+    uint32_t nan_pixels;     /* samples scrubbed by the film accumulate       */
+    uint32_t queue_sizes[PT_MAX_TRACKED_BOUNCES]; /* extension queue per bounce */
+    double ms_closest, ms_any, ms_generate, ms_shade, ms_film; /* summed ms   */
+    uint32_t n_closest, n_any, n_generate, n_shade, n_film;    /* launches    */
+} pt_stats;
+
+typedef struct pt_ctx pt_ctx;
+
+/* ---------------------------------------------------------------- lifecycle */
+
+/* Creates a context on HIP device `device` with its own stream. */
+int pt_ctx_create(int device, pt_ctx **out);
+void pt_ctx_destroy(pt_ctx *ctx);
+/* Message of the last failing call on ctx (ctx == NULL: last failing create). */
+const char *pt_last_error(const pt_ctx *ctx);
+/* Library version string. */
+const char *pt_version(void);
+/* Use a caller-owned hipStream_t for all later work (NULL = the ctx's own). */
+int pt_set_stream(pt_ctx *ctx, void *hip_stream);
+int pt_synchronize(pt_ctx *ctx);
+/* Bracket each kernel class with HIP events on the stream and sum into pt_stats. */
+int pt_set_profiling(pt_ctx *ctx, int enabled);
+int pt_get_stats(pt_ctx *ctx, pt_stats *out);
+int pt_reset_stats(pt_ctx *ctx);
+
+/* ---------------------------------------------------- scene upload (re-pack) */
+
+/* Replaces Scene::UpdateDevice (scene.cpp:52-96), TLAS::UpdateDevice
+ * (bvh.cpp:334-352), TexturePool::UpdateDevice (texture.cpp:76-109),
+ * DiscreteSampler1D::UpdateDevice (discrete_sampler.cpp:78-81) and
+ * Camera::UpdateDevice (camera.cpp:36-51): validates the description, re-packs
+ * BVH / triangles / instances for gfx950 and uploads everything.             */
+int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *desc);
+/* Replaces Camera::UpdateDevice (camera.cpp:36-51) for a camera-only change. */
+int pt_camera_update(pt_ctx *ctx, const pt_camera *camera);
+/* Replaces Scene::~Scene / TLAS::FreeDevice / TexturePool::FreeDevice
+ * (scene.cpp:22-50, bvh.cpp:354-365, texture.cpp:111-129).                   */
+int pt_scene_free(pt_ctx *ctx);
+
+/* -------------------------------------------------------------- integrator */
+
+/* Replace PathIntegrator::Init / Destroy / Resize / Reset
+ * (kernel/integrators/path_trace.cu:16-74).                                  */
+int pt_integrator_init(pt_ctx *ctx, int width, int height);
+int pt_integrator_destroy(pt_ctx *ctx);
+int pt_integrator_resize(pt_ctx *ctx, int width, int height);
+int pt_integrator_reset(pt_ctx *ctx, int width, int height);
+
+/* Replaces PathIntegrator::Render (path_trace.cu:436-483): one sample per
+ * pixel for `iteration`, film accumulate, then display = film/(iteration+1)
+ * -> ACES -> 8-bit into rgba_device (W*H uchar4 DEVICE pointer, caller-owned
+ * like the reference's `data`; NULL skips the display pass). Synchronous.     */
+int pt_render(pt_ctx *ctx, int width, int height, int iteration, uint8_t *rgba_device);
+/* Same, without the trailing host synchronisation (for back-to-back samples). */
+int pt_render_async(pt_ctx *ctx, int width, int height, int iteration, uint8_t *rgba_device);
+
+/* Film access (the reference keeps m_image private; the headless path and the
+ * multi-GPU reduce need it). rgb = W*H*3 fp32, row-major.                     */
+int pt_film_download(pt_ctx *ctx, float *rgb_host);
+int pt_film_copy_to_device(pt_ctx *ctx, float *rgb_device);
+int pt_film_copy_from_device(pt_ctx *ctx, const float *rgb_device);
+/* PostprocessAndUpload (path_trace.cu:409-434) on an arbitrary device film:
+ * out = quantise(ACES(film / iterations)). film_device NULL = the ctx's film. */
+int pt_tonemap(pt_ctx *ctx, const float *film_device, int width, int height, int iterations,
+               uint8_t *rgba_device);
+
+/* ------------------------------------------------- batch ray queries (metric) */
+
+/* IntersectScene<CLOSEST> (kernel/intersection.h:154-235) over n rays.
+ * rays / hits are DEVICE pointers, 16-B aligned.                             */
+int pt_trace_closest(pt_ctx *ctx, const pt_ray *rays_device, size_t n, pt_hit *hits_device);
+/* IntersectScene<ANY> with t_max = ray.tmax; occluded[i] = 1 on any hit. */
+int pt_trace_any(pt_ctx *ctx, const pt_ray *rays_device, size_t n, uint8_t *occluded_device);
+/* Expands hit records to the reference's Intersection (pos, shading normal, uv,
+ * material, geometry; kernel/intersection.h:96-99,145-149).                  */
+int pt_resolve_hits(pt_ctx *ctx, const pt_ray *rays_device, const pt_hit *hits_device, size_t n,
+                    pt_intersection *out_device);
+/* pt_trace_closest that also writes four visit counters per ray (interior nodes expanded,
+ * TLAS leaves entered, triangles tested, BLAS leaves visited): the reference's traversal
+ * callback hook (kernel/intersection.h:24-31,61,181) as a query. counters4 = n * 4 uint32. */
+int pt_trace_closest_counted(pt_ctx *ctx, const pt_ray *rays_device, size_t n, pt_hit *hits_device,
+                             uint32_t *counters4_device);
+/* Host-pointer conveniences (stage through device memory, synchronous). */
+int pt_trace_closest_host(pt_ctx *ctx, const pt_ray *rays, size_t n, pt_hit *hits);
+int pt_trace_any_host(pt_ctx *ctx, const pt_ray *rays, size_t n, uint8_t *occluded);
+int pt_resolve_hits_host(pt_ctx *ctx, const pt_ray *rays, const pt_hit *hits, size_t n,
+                         pt_intersection *out);
+
+/* Fills n incoherent rays on the device: origin uniform in the scene's root
+ * box scaled 1.1x about its centre, direction uniform on the sphere, tmax
+ * FLT_MAX, drawn from the per-ray PCG stream state = (i << 32) | 0xdeadbeef
+ * (i = first_index + ray number).                                             */
+int pt_generate_incoherent_rays(pt_ctx *ctx, pt_ray *rays_device, size_t n, uint64_t first_index);
+/* Captures the extension-ray queue of `bounce` (0 = camera rays) of `iteration`
+ * into rays_device (capacity rays); *count receives the number written.       */
+int pt_capture_bounce_rays(pt_ctx *ctx, int width, int height, int iteration, int bounce,
+                           pt_ray *rays_device, size_t capacity, size_t *count);
+
+/* Traversal variant: 0 = reference-exact ordering (default), 1 = fast
+ * (cross-instance culling with the global best t; ids may differ at exact ties). */
+int pt_set_trace_mode(pt_ctx *ctx, int mode);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTAMD_H */

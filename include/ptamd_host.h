@@ -1,0 +1,89 @@
+/*
+ * ptamd_host.h - C wrappers over the host C++ facade (cuda-path-tracer_amd/host),
+ * so that language bindings (the Python test-suite, bench.py) can drive the same
+ * Scene / TLAS / Camera / DiscreteSampler1D / PathIntegrator objects a C++ user
+ * links against.  None of these calls touches the GPU except pth_scene_update_device
+ * and the pth_integrator_* family, which forward to include/ptamd.h.
+ *
+ * Every function returns PT_OK or an error code; pth_last_error() holds the message
+ * of the last failing pth_* call of the calling thread.  Citations are file:line in
+ * the reference tree (src/...).
+ */
+#ifndef PTAMD_HOST_H
+#define PTAMD_HOST_H
+
+#include "ptamd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pth_scene pth_scene;
+typedef struct pth_integrator pth_integrator;
+
+const char *pth_last_error(void);
+
+/* ---- math helpers with glm's operation order (math/transform.cpp:5-14, scene.cpp:415-417) */
+int pth_transform_matrix(const float translate[3], const float rotate_deg[3], const float scale[3], float out[16]);
+int pth_matrix_derive(const float transform[16], float inv_transform[16], float inv_transpose[16]);
+int pth_matrix_mul(const float a[16], const float b[16], float out[16]);
+/* glTF node matrix: translate * mat4(quat xyzw) * scale * matrix (mesh/gltf_model.h:56-64). */
+int pth_gltf_local_matrix(const float translation[3], const float rotation_xyzw[4], const float scale[3],
+                          const float matrix[16], float out[16]);
+
+/* ---- DiscreteSampler1D::UpdateWeights (discrete_sampler.cpp:14-76) */
+int pth_alias_build(const float *weights, uint32_t n, float *probability_table, uint32_t *alias_table);
+
+/* ---- Camera::Update (camera.cpp:6-20) + Camera::UpdateDevice (:36-51) */
+int pth_camera_make(const float eye[3], const float look_at[3], const float up[3], float fovy_deg, int width,
+                    int height, pt_camera *out);
+
+/* ---- TLAS::Build (bvh.cpp:206-332) on raw arrays; arrays are copied out with pth_bvh_get */
+typedef struct pth_bvh pth_bvh;
+int pth_bvh_build(const float *positions, const uint32_t *indices, const pt_geometry_instance *instances, uint32_t n,
+                  pth_bvh **out);
+int pth_bvh_sizes(const pth_bvh *bvh, uint32_t *tlas_nodes, uint32_t *blases, uint32_t *blas_nodes, uint32_t *tri_indices);
+int pth_bvh_get(const pth_bvh *bvh, pt_tlas_node *tlas_nodes, pt_blas *blases, pt_bvh_node *blas_nodes, uint32_t *tri_indices);
+void pth_bvh_free(pth_bvh *bvh);
+
+/* ---- Scene (scene.h:23-186), filled programmatically */
+int pth_scene_create(pth_scene **out); /* runs InitDefaults (scene.cpp:235-260) */
+void pth_scene_destroy(pth_scene *scene);
+int pth_scene_set_integrator(pth_scene *scene, int max_depth, int max_iterations);
+int pth_scene_set_camera(pth_scene *scene, const float eye[3], const float look_at[3], const float up[3], float fovy_deg,
+                         int width, int height);
+/* returns the mesh's first_index through *first_index (index_count / vertex_count are the inputs) */
+int pth_scene_add_mesh(pth_scene *scene, const float *positions, const float *normals, const float *uvs,
+                       uint32_t vertex_count, const uint32_t *indices, uint32_t index_count, uint32_t *first_index);
+int pth_scene_add_material(pth_scene *scene, const pt_material *material, int *material_id);
+int pth_scene_add_texture1(pth_scene *scene, const pt_texture1 *texture, int *texture_id);
+int pth_scene_add_texture3(pth_scene *scene, const pt_texture3 *texture, int *texture_id);
+int pth_scene_add_image(pth_scene *scene, const float *texels, int width, int height, int channels, int srgb, int *image_id);
+int pth_scene_new_blas_index(pth_scene *scene, int *blas_index);
+int pth_scene_add_instance(pth_scene *scene, uint32_t first_index, uint32_t index_count, uint32_t vertex_count,
+                           int material_id, const float transform[16], int blas_index, int *instance_id);
+/* TLAS::Build + ComputeLightData (scene.cpp:676-686, :580-647) */
+int pth_scene_finalize(pth_scene *scene);
+/* host-pointer description, valid until the scene changes or is destroyed */
+int pth_scene_get_desc(pth_scene *scene, pt_scene_desc *out);
+/* Scene::UpdateDevice (scene.cpp:52-96) */
+int pth_scene_update_device(pth_scene *scene, pt_ctx *ctx);
+
+/* ---- PathIntegrator (kernel/integrators/path_trace.h:82-116) */
+int pth_integrator_create(pt_ctx *ctx, pth_integrator **out);
+void pth_integrator_destroy(pth_integrator *integrator);
+int pth_integrator_init(pth_integrator *integrator, int width, int height);
+int pth_integrator_resize(pth_integrator *integrator, int width, int height);
+int pth_integrator_reset(pth_integrator *integrator, int width, int height);
+int pth_integrator_render(pth_integrator *integrator, int width, int height, pth_scene *scene, uint8_t *rgba_device,
+                          int iteration);
+
+/* ---- headless output replacing the display path (application.cpp:157-179, image.cpp:105-139):
+ * writes an 8-bit RGB PNG (stored-deflate) or a Radiance .hdr of a fp32 film / iterations. */
+int pth_save_png(const char *path, const uint8_t *rgba, int width, int height);
+int pth_save_hdr(const char *path, const float *film_rgb, int width, int height, int iterations);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTAMD_HOST_H */
