@@ -148,6 +148,13 @@ def load_library() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension has not been built. "
             "Run `python -c \"import __graft_entry__ as g; g.build()\"` (needs hipcc); there is no CPU fallback.")
+    # One process must hold ONE HIP/HSA runtime: PyTorch-ROCm bundles its own libamdhip64.so, and
+    # whichever runtime initialises second finds no device.  Importing torch first makes the
+    # dynamic loader satisfy libptamd.so's libamdhip64 dependency with torch's copy.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i32, u32, u64, f32 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_float
     fp = C.POINTER(C.c_float)

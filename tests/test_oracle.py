@@ -1,0 +1,251 @@
+"""Pins the CPU oracle itself.  The reference ships no tests or golden vectors and cannot be
+compiled in this image (parity unpinned), so the oracle is checked against what can be known
+independently: closed-form intersections, integer-exact PCG values computed in Python, the
+brute-force all-triangles search (the reference's own cross-check), structural BVH invariants
+and alias-table reconstruction of the input distribution."""
+import numpy as np
+import pytest
+
+from conftest import rays_from_arrays
+
+FLT_MAX = np.float32(3.4028235e38)
+
+
+# ---------------------------------------------------------------- slab test (math/intersection.h:9-35)
+def test_aabb_known_answers(ora):
+    lo, hi = [-1, -1, -1], [1, 1, 1]
+    hit, t = ora.intersect_aabb([0, 0, -5], [0, 0, 1], lo, hi)
+    assert hit and t == 4.0
+    hit, t = ora.intersect_aabb([0, 0, 0], [0, 0, 1], lo, hi)  # origin inside: tnear negative
+    assert hit and t == -1.0
+    assert not ora.intersect_aabb([0, 0, 5], [0, 0, 1], lo, hi)[0]  # box behind the ray (tfar <= 0)
+    assert not ora.intersect_aabb([0, 0, -5], [0, 0, 1], lo, hi, t_max=3.5)[0]  # tnear >= t_max
+    assert ora.intersect_aabb([0, 0, -5], [0, 0, 1], lo, hi, t_max=4.5)[0]
+    assert not ora.intersect_aabb([2, 0, -5], [0, 0, 1], lo, hi)[0]  # parallel miss, inv_d = inf
+    # axis-parallel ray lying exactly in a face plane: 0 * inf = NaN, fminf/fmaxf keep the other
+    # operand (-inf on the max face, +inf on the min face), so the slab closes and the ray misses
+    assert not ora.intersect_aabb([1, 0, -5], [0, 0, 1], lo, hi)[0]
+    assert not ora.intersect_aabb([-1, 0, -5], [0, 0, 1], lo, hi)[0]
+    # ... while a ray just inside the face hits
+    hit, t = ora.intersect_aabb([0.999, 0, -5], [0, 0, 1], lo, hi)
+    assert hit and t == 4.0
+    # diagonal through a corner
+    d = np.array([1, 1, 1], np.float32) / np.sqrt(np.float32(3))
+    hit, t = ora.intersect_aabb([-3, -3, -3], d, lo, hi)
+    assert hit and abs(t - 2 * np.sqrt(3)) < 1e-5
+
+
+# -------------------------------------------------- Moeller-Trumbore (math/intersection.h:37-71)
+def test_triangle_known_answers(ora):
+    v0, v1, v2 = [0, 0, 0], [1, 0, 0], [0, 1, 0]
+    hit, t, u, v = ora.intersect_triangle([0.25, 0.5, 2], [0, 0, -1], v0, v1, v2)
+    assert hit and t == 2.0 and u == 0.25 and v == 0.5
+    hit, t, u, v = ora.intersect_triangle([0.25, 0.5, -2], [0, 0, 1], v0, v1, v2)  # two-sided
+    assert hit and t == 2.0
+    assert not ora.intersect_triangle([0.25, 0.5, 2], [1, 0, 0], v0, v1, v2)[0]  # parallel: |det| < 1e-9
+    assert not ora.intersect_triangle([0.25, 0.5, -2], [0, 0, -1], v0, v1, v2)[0]  # behind: t <= 1e-9
+    assert not ora.intersect_triangle([0.25, 0.5, 2], [0, 0, -1], v0, v1, v2, t_max=1.5)[0]  # t > t_max
+    assert ora.intersect_triangle([0.25, 0.5, 2], [0, 0, -1], v0, v1, v2, t_max=2.0)[0]  # t == t_max accepted
+    # edges and vertices are inclusive (u, v in [0,1], u+v <= 1)
+    assert ora.intersect_triangle([0.5, 0.5, 1], [0, 0, -1], v0, v1, v2)[0]  # on the hypotenuse
+    assert ora.intersect_triangle([0, 0, 1], [0, 0, -1], v0, v1, v2)[0]  # vertex 0
+    assert ora.intersect_triangle([1, 0, 1], [0, 0, -1], v0, v1, v2)[0]  # vertex 1
+    assert not ora.intersect_triangle([0.51, 0.5, 1], [0, 0, -1], v0, v1, v2)[0]
+    assert not ora.intersect_triangle([-1e-3, 0.5, 1], [0, 0, -1], v0, v1, v2)[0]
+    # a ray through the shared edge of two triangles hits both (no cracks)
+    a = ora.intersect_triangle([0.5, 0.5, 1], [0, 0, -1], [0, 0, 0], [1, 0, 0], [0, 1, 0])[0]
+    b = ora.intersect_triangle([0.5, 0.5, 1], [0, 0, -1], [1, 1, 0], [0, 1, 0], [1, 0, 0])[0]
+    assert a and b
+
+
+# -------------------------------------------------------------- PCG stream (independent.h:14-32)
+def _pcg_reference(px, py, iteration, n):
+    M32, M64 = (1 << 32) - 1, (1 << 64) - 1
+    key = ((px & 0xFFFF) | ((py & 0xFFFF) << 16)) ^ ((iteration * 0x9E3779B9) & M32)
+    state = (key * 747796405 + 2891336453) & M32
+    word = (((state >> ((state >> 28) + 4)) ^ state) * 277803737) & M32
+    hashed = ((word >> 22) ^ word) & M32
+    s = ((hashed << 32) | (hashed ^ 0xDEADBEEF)) & M64
+    out = []
+    for _ in range(n):
+        old = s
+        s = (old * 6364136223846793005 + 1) & M64
+        x = (((old >> 18) ^ old) >> 27) & M32
+        r = old >> 59
+        v = ((x >> r) | (x << ((-r) & 31))) & M32
+        out.append(np.float32(v) * np.float32(1.0 / 4294967296.0))
+    return np.array(out, np.float32)
+
+
+@pytest.mark.parametrize("px,py,it", [(0, 0, 0), (17, 5, 3), (1919, 1079, 8123), (65535, 65535, 1)])
+def test_pcg_stream_integer_exact(ora, px, py, it):
+    assert np.array_equal(ora.pcg_stream(px, py, it, 64), _pcg_reference(px, py, it, 64))
+
+
+# ------------------------------------------------------------ alias tables (discrete_sampler.cpp)
+@pytest.mark.parametrize("weights", [[1.0], [1, 1, 1, 1], [0.1, 0.2, 0.3, 0.4], [5, 0, 0, 1], list(np.linspace(0.01, 3, 97))])
+def test_alias_table_reconstructs_distribution(ora, weights):
+    w = np.asarray(weights, np.float32)
+    st, prob, alias = ora.alias_build(w)
+    assert st == 0
+    n = len(w)
+    mass = np.zeros(n, np.float64)
+    for i in range(n):
+        mass[i] += prob[i] / n
+        if prob[i] < 1.0:
+            assert alias[i] < n
+            mass[alias[i]] += (1.0 - prob[i]) / n
+    assert np.allclose(mass, w / w.sum(), atol=3e-5)
+
+
+def test_alias_table_rejects_zero_sum(ora):
+    st, _, _ = ora.alias_build([0.0, 0.0])
+    assert st != 0
+
+
+# ------------------------------------------------------------------ BVH structure (bvh.cpp:5-332)
+def _check_bvh(arr):
+    geos, blases, nodes, tri = arr["geometries"], arr["blases"], arr["blas_nodes"], arr["tri_indices"]
+    pos, idx = arr["positions"], arr["indices"]
+    done = set()
+    for g in geos:
+        if int(g["blas_index"]) in done:
+            continue
+        done.add(int(g["blas_index"]))
+        b = blases[g["blas_index"]]
+        assert b["node_count"] > 0 and b["index_count"] == g["index_count"] // 3
+        perm = tri[b["first_index"]: b["first_index"] + b["index_count"]]
+        assert np.array_equal(np.sort(perm), np.arange(b["index_count"], dtype=np.uint32))  # a permutation
+        seen = np.zeros(b["index_count"], bool)
+        stack = [int(b["first_node"])]
+        visited = 0
+        while stack:
+            k = stack.pop()
+            visited += 1
+            n = nodes[k]
+            if n["primitive_count"] > 0:
+                rng = slice(int(n["first_primitive"]), int(n["first_primitive"] + n["primitive_count"]))
+                assert not seen[rng].any()
+                seen[rng] = True
+                tris = perm[rng]
+                vid = idx[g["first_index"] + (tris[:, None] * 3 + np.arange(3)[None, :])].reshape(-1)
+                p = pos[vid]
+                assert np.array_equal(p.min(axis=0), n["min"]) and np.array_equal(p.max(axis=0), n["max"])  # tight
+            else:
+                l, r = int(n["first_primitive"]), int(n["first_primitive"]) + 1
+                assert l > k  # children are allocated after their parent, adjacently
+                assert np.array_equal(np.minimum(nodes[l]["min"], nodes[r]["min"]), n["min"])
+                assert np.array_equal(np.maximum(nodes[l]["max"], nodes[r]["max"]), n["max"])
+                stack += [l, r]
+        assert seen.all() and visited == b["node_count"]
+    # TLAS: slot 0 is the root copy, leaves 1..n in instance order, every instance reachable once
+    tl = arr["tlas_nodes"]
+    n = len(geos)
+    assert len(tl) == 2 * n
+    for i in range(n):
+        assert tl[1 + i]["left_right"] == 0 and tl[1 + i]["instance"] == i
+    reach = []
+    stack = [0]
+    while stack:
+        node = tl[stack.pop()]
+        if node["left_right"] == 0:
+            reach.append(int(node["instance"]))
+        else:
+            stack += [int(node["left_right"] & 0xFFFF), int(node["left_right"] >> 16)]
+    assert sorted(reach) == list(range(n))
+
+
+@pytest.mark.parametrize("name", ["teapot", "cornell", "instancing_stress"])
+def test_oracle_bvh_invariants(ora, scene_factory, name):
+    hs = scene_factory(name, 64, 64, 4)
+    arr = hs.arrays()
+    built = ora.tlas_build(arr["positions"], arr["indices"], arr["geometries"])
+    arr.update(built)
+    _check_bvh(arr)
+
+
+# ------------------------------------------------------------- traversal vs brute force (naive)
+@pytest.mark.parametrize("name", ["teapot", "cornell", "tiny"])
+def test_oracle_bvh_traversal_equals_brute_force(ora, pt, scene_factory, tiny_scene, name):
+    hs = tiny_scene if name == "tiny" else scene_factory(name, 64, 64, 4)
+    d = hs.desc()
+    n = 1500 if name == "teapot" else 4000
+    rays = ora.generate_incoherent_rays(d, n, 11)
+    hits = ora.trace_closest(d, rays, nthreads=4)
+    naive = ora.trace_naive(d, rays, nthreads=4)
+    assert np.array_equal(hits["inst"] >= 0, naive["inst"] >= 0)
+    both = hits["inst"] >= 0
+    assert both.sum() > n // 10
+    # same winner except where two candidates are within rounding of each other
+    same = (hits["prim"] == naive["prim"]) & (hits["inst"] == naive["inst"])
+    rel = np.abs(hits["t"] - naive["t"]) / np.maximum(np.abs(naive["t"]), 1e-20)
+    assert (rel[both] < 2e-5).all()
+    assert (~same[both]).sum() <= max(1, both.sum() // 200)
+    # any-hit agrees with "closest hit exists within tmax" away from the boundary
+    rays_any = rays.copy()
+    rays_any["tmax"] = np.where(both, hits["t"] * np.float32(1.5), np.float32(10.0))
+    occ = ora.trace_any(d, rays_any, nthreads=4)
+    assert np.array_equal(occ.astype(bool), both)
+    rays_any["tmax"] = np.where(both, hits["t"] * np.float32(0.5), np.float32(10.0))
+    occ = ora.trace_any(d, rays_any, nthreads=4)
+    assert not occ.any()
+
+
+def test_oracle_sphere_analytic(ora, pt, scene_factory):
+    """Closest hits on the tessellated radius-0.5 sphere (scaled 3x, centred at (-1,4,-1) in the
+    legacy cornell scene) stay within the tessellation error of the analytic sphere."""
+    hs = scene_factory("cornell", 64, 64, 4)
+    d = hs.desc()
+    arr = hs.arrays()
+    # instance 6 is the first sphere of Scenes/cornell.json
+    g = arr["geometries"][6]
+    T = g["transform"].reshape(4, 4).T
+    centre = T[:3, 3]
+    radius = 0.5 * T[0, 0]
+    rs = np.random.RandomState(3)
+    dirs = rs.normal(size=(2000, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    origins = (centre[None, :] + 0.05 * rs.normal(size=(2000, 3))).astype(np.float32)  # inside the sphere
+    hits = ora.trace_closest(d, rays_from_arrays(pt, origins, dirs), nthreads=4)
+    inside = hits["inst"] == 6
+    assert inside.mean() > 0.99
+    p = origins + hits["t"][:, None] * dirs
+    dist = np.linalg.norm(p - centre[None, :], axis=1)
+    assert (np.abs(dist[inside] - radius) < 0.004 * radius + 1e-4).all()
+
+
+# --------------------------------------------------------------------- camera and tone map
+def test_camera_rays(ora):
+    cam = ora.camera_update([0, 0, 5], [0, 0, 0], [0, 1, 0], 90.0, 4, 2)
+    assert np.allclose(list(cam.front), [0, 0, -1]) and np.allclose(list(cam.right), [1, 0, 0]) and np.allclose(list(cam.up), [0, 1, 0])
+    # fovy 90 -> half height 1, aspect 2 -> pixel length 1 in both axes
+    assert np.allclose(list(cam.pixel_length), [1.0, 1.0])
+    import ctypes as C
+    o, dr = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    fp = C.POINTER(C.c_float)
+    ora.lib().ora_camera_ray(C.byref(cam), 2, 1, 0.0, 0.0, o.ctypes.data_as(fp), dr.ctypes.data_as(fp))
+    assert np.allclose(o, [0, 0, 5]) and np.allclose(dr, [0, 0, -1])  # pixel (W/2, H/2) corner = optical axis
+    ora.lib().ora_camera_ray(C.byref(cam), 0, 0, 0.0, 0.0, o.ctypes.data_as(fp), dr.ctypes.data_as(fp))
+    assert np.allclose(dr, np.array([-2, 1, -1]) / np.sqrt(6), atol=1e-6)  # image y points down
+
+
+def test_tonemap_known_values(ora):
+    film = np.zeros((1, 4, 3), np.float32)
+    film[0, 0] = 0.0
+    film[0, 1] = 2.0   # two iterations -> radiance 1.0
+    film[0, 2] = 2000.0
+    film[0, 3] = [0.36, 0.36, 0.36]
+    out = ora.tonemap(film, iteration=1)
+    aces = lambda x: min(max((x * (2.51 * x + 0.03)) / (x * (2.43 * x + 0.59) + 0.14), 0.0), 1.0)
+    assert list(out[0, 0]) == [0, 0, 0, 255]
+    assert out[0, 1, 0] == int(aces(1.0) * 255.0)
+    assert out[0, 2, 0] == 255
+    assert out[0, 3, 0] == int(np.float32(aces(0.18)) * 255.0) or abs(int(out[0, 3, 0]) - int(aces(0.18) * 255.0)) <= 1
+
+
+def test_render_is_deterministic_and_thread_independent(ora, tiny_scene):
+    d = tiny_scene.desc()
+    a, sa = ora.render(d, 64, 48, 2, nthreads=1)
+    b, sb = ora.render(d, 64, 48, 2, nthreads=4)
+    assert np.array_equal(a, b) and sa == sb
+    assert np.isfinite(a).all() and a.mean() > 0.01
