@@ -70,35 +70,59 @@ PTD void flush_events(DevStats *stats, const LaneEvents &ev) {
 
 // ------------------------------------------------------------- batch queries
 template <bool COUNT>
+struct ClosestIO {
+    const DScene &S;
+    const pt_ray *rays;
+    pt_hit *hits;
+    TraceCounters *counters;
+    PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax) const {
+        const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
+        const float4 ro = rp[0], rd = rp[1];
+        o = mk3(ro.x, ro.y, ro.z);
+        d = mk3(rd.x, rd.y, rd.z);
+        tmax = rd.w;
+        return true;
+    }
+    PTD void done(uint32_t i, const Traversal<MODE_CLOSEST, COUNT> &tr, bool hit) const {
+        int prim = -1, mat = -1;
+        if (hit) {
+            prim = int(as_u(reinterpret_cast<const float4 *>(S.tris + tr.hit.rec)[2].y));
+            mat = int(as_u(reinterpret_cast<const float4 *>(S.insts + tr.hit.inst)[3].y));
+        }
+        float4 *hp = reinterpret_cast<float4 *>(hits + i);
+        hp[0] = make_float4(hit ? tr.hit.t : -1.0f, hit ? tr.hit.u : 0.0f, hit ? tr.hit.v : 0.0f, as_f(uint32_t(prim)));
+        hp[1] = make_float4(as_f(uint32_t(hit ? tr.hit.inst : -1)), as_f(uint32_t(mat)), 0.0f, 0.0f);
+        if (COUNT) counters[i] = tr.ctr;
+    }
+    PTD void flush() const {}
+};
+
+template <bool COUNT>
 __global__ __launch_bounds__(64) void k_trace_closest(DScene S, const pt_ray *rays, uint32_t n, pt_hit *hits, uint32_t *cursor,
                                                       uint2 *spill, uint32_t spill_stride, DevStats *stats, TraceCounters *counters) {
     __shared__ uint2 lds[kLdsDepth * kWave];
     const uint32_t lane = threadIdx.x;
     const LaneStack stk{lds + lane, spill + size_t(blockIdx.x) * kWave + lane, spill_stride};
     LaneEvents ev;
-    for (;;) {
-        const uint32_t base = wave_fetch(cursor, kWave);
-        if (base >= n) break;
-        const uint32_t i = base + lane;
-        if (i < n) {
-            const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
-            const float4 ro = rp[0], rd = rp[1];
-            HitRec h;
-            TraceCounters c{0, 0, 0, 0};
-            const bool hit = trace_ray<MODE_CLOSEST, COUNT>(S, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), rd.w, stk, h, ev, c);
-            int prim = -1, mat = -1;
-            if (hit) {
-                prim = int(as_u(reinterpret_cast<const float4 *>(S.tris + h.rec)[2].y));
-                mat = int(as_u(reinterpret_cast<const float4 *>(S.insts + h.inst)[3].y));
-            }
-            float4 *hp = reinterpret_cast<float4 *>(hits + i);
-            hp[0] = make_float4(hit ? h.t : -1.0f, hit ? h.u : 0.0f, hit ? h.v : 0.0f, as_f(uint32_t(prim)));
-            hp[1] = make_float4(as_f(uint32_t(hit ? h.inst : -1)), as_f(uint32_t(mat)), 0.0f, 0.0f);
-            if (COUNT) counters[i] = c;
-        }
-    }
+    ClosestIO<COUNT> io{S, rays, hits, counters};
+    trace_stream<MODE_CLOSEST, COUNT>(S, io, n, cursor, stk, ev);
     flush_events(stats, ev);
 }
+
+struct AnyIO {
+    const pt_ray *rays;
+    uint8_t *occluded;
+    PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax) const {
+        const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
+        const float4 ro = rp[0], rd = rp[1];
+        o = mk3(ro.x, ro.y, ro.z);
+        d = mk3(rd.x, rd.y, rd.z);
+        tmax = rd.w;
+        return true;
+    }
+    PTD void done(uint32_t i, const Traversal<MODE_ANY, false> &, bool hit) const { occluded[i] = hit ? 1 : 0; }
+    PTD void flush() const {}
+};
 
 __global__ __launch_bounds__(64) void k_trace_any(DScene S, const pt_ray *rays, uint32_t n, uint8_t *occluded, uint32_t *cursor,
                                                   uint2 *spill, uint32_t spill_stride, DevStats *stats) {
@@ -106,19 +130,8 @@ __global__ __launch_bounds__(64) void k_trace_any(DScene S, const pt_ray *rays, 
     const uint32_t lane = threadIdx.x;
     const LaneStack stk{lds + lane, spill + size_t(blockIdx.x) * kWave + lane, spill_stride};
     LaneEvents ev;
-    for (;;) {
-        const uint32_t base = wave_fetch(cursor, kWave);
-        if (base >= n) break;
-        const uint32_t i = base + lane;
-        if (i < n) {
-            const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
-            const float4 ro = rp[0], rd = rp[1];
-            HitRec h;
-            TraceCounters c{0, 0, 0, 0};
-            const bool hit = trace_ray<MODE_ANY, false>(S, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), rd.w, stk, h, ev, c);
-            occluded[i] = hit ? 1 : 0;
-        }
-    }
+    AnyIO io{rays, occluded};
+    trace_stream<MODE_ANY, false>(S, io, n, cursor, stk, ev);
     flush_events(stats, ev);
 }
 
@@ -217,49 +230,79 @@ __global__ __launch_bounds__(64) void k_generate(DScene S, PathState P, BounceCo
         P.accum[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         P.rng[slot] = make_uint2(uint32_t(rng), uint32_t(rng >> 32));
     }
-    const uint32_t q = wave_append(&cnt[0].ext_count, active);
-    if (active) P.ext_q[0][q] = slot;
+    // bounce 0 needs no queue: its extension "queue" is the identity over all path slots
+    if (slot == 0) cnt[0].ext_count = gridDim.x * kWave;
 }
 
 // IntersectClosestKernel, path_trace.cu:110-179: closest hit + classification by material type.
-__global__ __launch_bounds__(64) void k_extend(DScene S, PathState P, BounceCounters *cnt, int bounce, uint2 *spill,
+// A miss ends the path on the spot (the reference routes it through EmissiveHitKernel, which adds
+// throughput * 0, path_trace.cu:351-356: a no-op unless the throughput is not finite).
+struct ExtendIO {
+    const DScene &S;
+    const PathState &P;
+    BounceCounters *bc;
+    const uint32_t *queue;  // null: identity (bounce 0)
+    int width, height;
+    bool pending = false;
+    uint32_t pend_slot = 0;
+    int pend_cls = 0;
+    uint32_t slot = 0;
+    PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax) {
+        if (queue) {
+            slot = queue[i];
+        } else {
+            slot = i;
+            int x, y;
+            if (!slot_to_pixel(slot, width, height, x, y)) return false;
+        }
+        const float4 ro = P.ray_o[slot], rd = P.ray_d[slot];
+        o = mk3(ro.x, ro.y, ro.z);
+        d = mk3(rd.x, rd.y, rd.z);
+        tmax = FLT_MAX;
+        return true;
+    }
+    PTD void done(uint32_t, const Traversal<MODE_CLOSEST, false> &tr, bool hit) {
+        P.hit_inst[slot] = hit ? tr.hit.inst : -1;
+        if (!hit) {
+            const float4 t = P.thr[slot];
+            const float z = t.x * 0.0f + t.y * 0.0f + t.z * 0.0f;  // NaN iff the throughput is not finite
+            if (z != z) {
+                float4 a = P.accum[slot];
+                a.x += t.x * 0.0f;
+                a.y += t.y * 0.0f;
+                a.z += t.z * 0.0f;
+                P.accum[slot] = a;
+            }
+            return;
+        }
+        P.hit[slot] = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, as_f(tr.hit.rec));
+        const uint32_t type = as_u(reinterpret_cast<const float4 *>(S.insts + tr.hit.inst)[3].z);
+        pend_cls = type == PT_MAT_LAMBERTIAN ? 1 : type == PT_MAT_MIRROR ? 2 : type == PT_MAT_METALLIC_ROUGHNESS ? 3
+                   : type == PT_MAT_DIELECTRIC ? 4 : 0;
+        pend_slot = slot;
+        pending = true;
+    }
+    PTD void flush() {
+        if (__ballot(pending) == 0) return;
+#pragma unroll
+        for (int k = 0; k < kNumClasses; ++k) {
+            const bool mine = pending && pend_cls == k;
+            const uint32_t q = wave_append(&bc->class_count[k], mine);
+            if (mine) P.class_q[k][q] = pend_slot;
+        }
+        pending = false;
+    }
+};
+
+__global__ __launch_bounds__(64) void k_extend(DScene S, PathState P, BounceCounters *cnt, int bounce, int width, int height, uint2 *spill,
                                                uint32_t spill_stride, DevStats *stats) {
     __shared__ uint2 lds[kLdsDepth * kWave];
     const uint32_t lane = threadIdx.x;
     const LaneStack stk{lds + lane, spill + size_t(blockIdx.x) * kWave + lane, spill_stride};
     BounceCounters *bc = cnt + bounce;
-    const uint32_t n = bc->ext_count;
-    const uint32_t *queue = P.ext_q[bounce & 1];
     LaneEvents ev;
-    for (;;) {
-        const uint32_t base = wave_fetch(&bc->cur_extend, kWave);
-        if (base >= n) break;
-        const uint32_t qi = base + lane;
-        const bool active = qi < n;
-        int cls = -1;
-        uint32_t slot = 0;
-        if (active) {
-            slot = queue[qi];
-            const float4 ro = P.ray_o[slot], rd = P.ray_d[slot];
-            HitRec h;
-            TraceCounters c{0, 0, 0, 0};
-            const bool hit = trace_ray<MODE_CLOSEST, false>(S, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), FLT_MAX, stk, h, ev, c);
-            P.hit[slot] = make_float4(h.t, h.u, h.v, as_f(h.rec));
-            P.hit_inst[slot] = hit ? h.inst : -1;
-            cls = 0;
-            if (hit) {
-                const uint32_t type = as_u(reinterpret_cast<const float4 *>(S.insts + h.inst)[3].z);
-                cls = type == PT_MAT_LAMBERTIAN ? 1 : type == PT_MAT_MIRROR ? 2 : type == PT_MAT_METALLIC_ROUGHNESS ? 3
-                      : type == PT_MAT_DIELECTRIC ? 4 : 0;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < kNumClasses; ++k) {
-            const bool mine = active && cls == k;
-            const uint32_t q = wave_append(&bc->class_count[k], mine);
-            if (mine) P.class_q[k][q] = slot;
-        }
-    }
+    ExtendIO io{S, P, bc, bounce == 0 ? nullptr : P.ext_q[bounce & 1], width, height};
+    trace_stream<MODE_CLOSEST, false>(S, io, bc->ext_count, &bc->cur_extend, stk, ev);
     flush_events(stats, ev);
 }
 
@@ -409,34 +452,39 @@ __global__ __launch_bounds__(64) void k_shade(DScene S, PathState P, BounceCount
 
 // The visibility half of next-event estimation (path_trace.cu:221-243): IntersectScene<ANY> with
 // t_max = dist - 1e-4; an unoccluded sample adds its contribution to the path's radiance.
+struct ShadowIO {
+    const PathState &P;
+    uint32_t slot = 0;
+    float4 contrib;
+    PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax) {
+        const float4 so = P.sh_o[i], sd = P.sh_d[i];
+        contrib = P.sh_c[i];
+        o = mk3(so.x, so.y, so.z);
+        d = mk3(sd.x, sd.y, sd.z);
+        tmax = so.w;
+        slot = as_u(sd.w);
+        return true;
+    }
+    PTD void done(uint32_t, const Traversal<MODE_ANY, false> &, bool occluded) const {
+        if (occluded) return;
+        float4 a = P.accum[slot];
+        a.x += contrib.x;
+        a.y += contrib.y;
+        a.z += contrib.z;
+        P.accum[slot] = a;
+    }
+    PTD void flush() const {}
+};
+
 __global__ __launch_bounds__(64) void k_shadow(DScene S, PathState P, BounceCounters *cnt, int bounce, uint2 *spill,
                                                uint32_t spill_stride, DevStats *stats) {
     __shared__ uint2 lds[kLdsDepth * kWave];
     const uint32_t lane = threadIdx.x;
     const LaneStack stk{lds + lane, spill + size_t(blockIdx.x) * kWave + lane, spill_stride};
     BounceCounters *bc = cnt + bounce;
-    const uint32_t n = bc->shadow_count;
     LaneEvents ev;
-    for (;;) {
-        const uint32_t base = wave_fetch(&bc->cur_shadow, kWave);
-        if (base >= n) break;
-        const uint32_t qi = base + lane;
-        if (qi < n) {
-            const float4 so = P.sh_o[qi], sd = P.sh_d[qi];
-            HitRec h;
-            TraceCounters c{0, 0, 0, 0};
-            const bool occluded = trace_ray<MODE_ANY, false>(S, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, stk, h, ev, c);
-            if (!occluded) {
-                const uint32_t slot = as_u(sd.w);
-                const float4 sc = P.sh_c[qi];
-                float4 a = P.accum[slot];
-                a.x += sc.x;
-                a.y += sc.y;
-                a.z += sc.z;
-                P.accum[slot] = a;
-            }
-        }
-    }
+    ShadowIO io{P};
+    trace_stream<MODE_ANY, false>(S, io, bc->shadow_count, &bc->cur_shadow, stk, ev);
     flush_events(stats, ev);
 }
 
@@ -475,11 +523,20 @@ __global__ void k_tonemap(const float *film, uint8_t *rgba, int width, int heigh
 }
 
 // Copies the extension rays of one bounce into a pt_ray buffer (queue order).
-__global__ void k_gather_rays(PathState P, const BounceCounters *cnt, int bounce, pt_ray *out, uint32_t capacity) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_gather_rays(PathState P, const BounceCounters *cnt, int bounce, pt_ray *out, uint32_t capacity, int width, int height) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = cnt[bounce].ext_count;
-    if (i >= n || i >= capacity) return;
-    const uint32_t slot = P.ext_q[bounce & 1][i];
+    if (i >= n) return;
+    uint32_t slot;
+    if (bounce == 0) {  // camera rays: every path slot, written in pixel order
+        slot = i;
+        int x, y;
+        if (!slot_to_pixel(slot, width, height, x, y)) return;
+        i = uint32_t(y) * uint32_t(width) + uint32_t(x);
+    } else {
+        slot = P.ext_q[bounce & 1][i];
+    }
+    if (i >= capacity) return;
     const float4 ro = P.ray_o[slot], rd = P.ray_d[slot];
     float4 *rp = reinterpret_cast<float4 *>(out + i);
     rp[0] = make_float4(ro.x, ro.y, ro.z, 0.0f);

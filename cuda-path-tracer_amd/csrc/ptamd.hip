@@ -425,6 +425,8 @@ int pt_get_stats(pt_ctx *ctx, pt_stats *out) {
         ctx->stats.shadow_rays = 0;
         ctx->stats.bounces_run = 0;
         std::memset(ctx->stats.queue_sizes, 0, sizeof(ctx->stats.queue_sizes));
+        // bounce 0 streams all path slots (8x8-tile padded); its real ray count is one per pixel
+        bc[0].ext_count = uint32_t(ctx->width) * uint32_t(ctx->height);
         for (int b = 0; b < ctx->last_render_bounces; ++b) {
             ctx->stats.closest_rays += bc[b].ext_count;
             ctx->stats.shadow_rays += bc[b].shadow_count;
@@ -786,7 +788,7 @@ static int RunBounces(pt_ctx *ctx, int width, int height, int iteration, int bou
         if (last && !shade_last) break;
         {
             ScopedEvent ev(ctx, EV_CLOSEST);
-            hipLaunchKernelGGL(k_extend, grid, block, 0, ctx->stream, S, P, ctx->counters, b, ctx->spill, ctx->spill_stride, ctx->dev_stats);
+            hipLaunchKernelGGL(k_extend, grid, block, 0, ctx->stream, S, P, ctx->counters, b, width, height, ctx->spill, ctx->spill_stride, ctx->dev_stats);
         }
         {
             ScopedEvent ev(ctx, EV_SHADE);
@@ -1025,13 +1027,17 @@ int pt_capture_bounce_rays(pt_ctx *ctx, int width, int height, int iteration, in
     if (st != PT_OK) return st;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned_word, &ctx->counters[bounce].ext_count, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const size_t n = std::min<size_t>(*ctx->pinned_word, capacity);
-    if (n > 0) {
-        hipLaunchKernelGGL(k_gather_rays, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->paths, ctx->counters, bounce, rays_device, uint32_t(capacity));
+    // bounce 0 streams every path slot (padded to 8x8 tiles) and writes the W*H camera rays in pixel order
+    const size_t launch_n = *ctx->pinned_word;
+    const size_t produced = bounce == 0 ? size_t(width) * size_t(height) : launch_n;
+    if (produced > capacity) return Fail(ctx, PT_ERR_LIMIT, "capture buffer holds %zu rays, %zu needed", capacity, produced);
+    if (launch_n > 0) {
+        hipLaunchKernelGGL(k_gather_rays, dim3(uint32_t((launch_n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->paths, ctx->counters, bounce, rays_device,
+                           uint32_t(capacity), width, height);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
-    *count = n;
+    *count = produced;
     return PT_OK;
 }
 

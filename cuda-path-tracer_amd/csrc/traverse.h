@@ -25,7 +25,7 @@
 
 namespace ptd {
 
-constexpr int kLdsDepth = 24;  // stack entries per lane held in LDS
+constexpr int kLdsDepth = 16;  // stack entries per lane held in LDS
 constexpr int kRefStack = 64;  // capacity of each of the reference's two stacks
 constexpr int kSpillDepth = 2 * kRefStack - kLdsDepth;
 constexpr int kWave = 64;
@@ -134,31 +134,60 @@ PTD V3 tri_point(const DTri *tris, uint32_t rec, float u, float v) {
     return w * p0 + u * p1 + v * p2;
 }
 
-// Traces one ray.  Returns true on a hit; for MODE_CLOSEST `hit` then holds the winner.
+// Per-lane traversal state.  begin() loads a ray and performs the root-box rejection;
+// step() runs one round of "descend to a leaf, process it, pop the next entry" and returns
+// true when the ray is finished.  Splitting the loop this way lets a persistent wave hand a
+// finished lane a new ray while its neighbours are still traversing.
 template <int MODE, bool COUNT>
-PTD bool trace_ray(const DScene &S, V3 o, V3 d, float t_max, const LaneStack &stk, HitRec &hit, LaneEvents &ev,
-                   TraceCounters &ctr) {
-    hit.t = -1.0f;
-    hit.u = hit.v = 0.0f;
-    hit.rec = 0;
-    hit.inst = -1;
-    const V3 iw = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    {
-        float t;
-        if (!slab(o, iw, S.root_min[0], S.root_min[1], S.root_min[2], S.root_max[0], S.root_max[1], S.root_max[2], t_max, t))
-            return false;  // kernel/intersection.h:162
-    }
-    V3 co = o, cd = d, ci = iw;  // ray in the current space (world, or the instance's object space)
-    float best = FLT_MAX;        // best world-space distance over finished instances
-    float lbest = FLT_MAX;       // best object-space distance inside the current instance
-    uint32_t lrec = 0;
-    float lu = 0.0f, lv = 0.0f;
-    int cur_inst = -1;
-    int sp = 0, base = 0;
-    bool in_blas = false;
-    uint32_t cur = S.root_ref;
+struct Traversal {
+    V3 o, d, iw;     // world-space ray and reciprocal direction
+    V3 co, cd, ci;   // ray in the current space (world, or the current instance's object space)
+    float t_max;
+    float best;      // best world-space distance over finished instances
+    float lbest;     // best object-space distance inside the current instance
+    uint32_t lrec;
+    float lu, lv;
+    int cur_inst;
+    int sp, base;
+    bool in_blas;
+    uint32_t cur;
+    HitRec hit;
+    bool found;      // MODE_ANY: an occluder was found
+    TraceCounters ctr;
 
-    for (;;) {
+    // Returns false when the ray misses the scene's root box (kernel/intersection.h:162).
+    PTD bool begin(const DScene &S, V3 origin, V3 dir, float tmax) {
+        o = origin;
+        d = dir;
+        t_max = tmax;
+        hit.t = -1.0f;
+        hit.u = hit.v = 0.0f;
+        hit.rec = 0;
+        hit.inst = -1;
+        found = false;
+        if (COUNT) ctr = TraceCounters{0, 0, 0, 0};
+        iw = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        float t;
+        if (!slab(o, iw, S.root_min[0], S.root_min[1], S.root_min[2], S.root_max[0], S.root_max[1], S.root_max[2], t_max, t)) return false;
+        co = o;
+        cd = d;
+        ci = iw;
+        best = FLT_MAX;
+        lbest = FLT_MAX;
+        lrec = 0;
+        lu = lv = 0.0f;
+        cur_inst = -1;
+        sp = 0;
+        base = 0;
+        in_blas = false;
+        cur = S.root_ref;
+        return true;
+    }
+
+    // True when a closest hit exists (valid after the last step; kernel/intersection.h:229-232).
+    PTD bool closest_valid() const { return !(best < 0.0f || best == FLT_MAX); }
+
+    PTD bool step(const DScene &S, const LaneStack &stk, LaneEvents &ev) {
         // ---- descend through interior nodes
         while (cur < kNoRef) {
             if (COUNT) ctr.interior++;
@@ -219,7 +248,7 @@ PTD bool trace_ray(const DScene &S, V3 o, V3 d, float t_max, const LaneStack &st
                 base = sp;
                 in_blas = true;
                 cur = as_u(in.d.x);
-                continue;
+                return false;
             }
             // ---- BLAS leaf: test its triangles in order (kernel/intersection.h:63-112)
             if (COUNT) ctr.blas_leaves++;
@@ -236,7 +265,10 @@ PTD bool trace_ray(const DScene &S, V3 o, V3 d, float t_max, const LaneStack &st
                 const float4 ta = tp[0], tb = tp[1], tc = tp[2];
                 float t, u, v;
                 if (!tri_test(co, cd, ta, tb, tc, t_max, t, u, v)) continue;
-                if (MODE == MODE_ANY) return true;
+                if (MODE == MODE_ANY) {
+                    found = true;
+                    return true;
+                }
                 if (t < lbest) {
                     lbest = t;
                     lrec = first + i;
@@ -248,7 +280,6 @@ PTD bool trace_ray(const DScene &S, V3 o, V3 d, float t_max, const LaneStack &st
         }
 
         // ---- pop the next entry, leaving the instance / finishing when a level runs dry
-        bool done = false;
         while (cur == kNoRef) {
             if (in_blas) {
                 if (sp == base) {
@@ -275,8 +306,7 @@ PTD bool trace_ray(const DScene &S, V3 o, V3 d, float t_max, const LaneStack &st
                     continue;
                 }
             } else if (sp == 0) {
-                done = true;
-                break;
+                return true;
             }
             --sp;
             const uint2 e = stack_load(stk, sp);
@@ -285,14 +315,70 @@ PTD bool trace_ray(const DScene &S, V3 o, V3 d, float t_max, const LaneStack &st
             }
             cur = e.x;
         }
-        if (done) break;
-    }
-    if (best < 0.0f || best == FLT_MAX) {  // kernel/intersection.h:229-232
-        hit.t = -1.0f;
-        hit.inst = -1;
         return false;
     }
-    return true;
+};
+
+// Streams `n` rays through a persistent wave: the wave pulls chunks of kFetchChunk ray indices
+// from a global cursor, and every lane that finishes its ray takes the next index of the
+// chunk while its neighbours keep traversing (refill happens once at least kRefillMin lanes
+// are idle, so the reload code runs for a meaningful share of the wave).
+//   io.load(i, o, d, tmax)              ray i of the stream
+//   io.done(i, trav, valid)             called once per ray by the lane that traced it
+//   io.flush(pending)                   called by all 64 lanes at every refill point
+constexpr uint32_t kFetchChunk = 256;
+constexpr int kRefillMin = 16;
+
+template <int MODE, bool COUNT, class IO>
+PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, const LaneStack &stk, LaneEvents &ev) {
+    Traversal<MODE, COUNT> tr;
+    bool active = false;
+    uint32_t ray_index = 0;
+    uint32_t pool_next = 0, pool_end = 0;  // wave-uniform
+    bool exhausted = false;                // wave-uniform
+    const uint32_t chunk = (n > kFetchChunk * 2u * gridDim.x) ? kFetchChunk : uint32_t(kWave);
+    for (;;) {
+        const uint64_t idle_mask = __ballot(!active);
+        const int idle = __popcll(idle_mask);
+        if (idle >= kRefillMin || idle == kWave) {
+            io.flush();
+            if (pool_next >= pool_end && !exhausted) {
+                uint32_t b = 0;
+                if ((threadIdx.x & 63) == 0) b = atomicAdd(cursor, chunk);
+                b = __shfl(b, 0, 64);
+                if (b >= n) {
+                    exhausted = true;
+                } else {
+                    pool_next = b;
+                    pool_end = (n - b < chunk) ? n : b + chunk;
+                }
+            }
+            if (pool_next < pool_end) {
+                const uint32_t prefix = __builtin_amdgcn_mbcnt_hi(uint32_t(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle_mask), 0u));
+                const uint32_t mine = pool_next + prefix;
+                if (!active && mine < pool_end) {
+                    V3 o, d;
+                    float tmax;
+                    if (io.load(mine, o, d, tmax)) {  // false: an unused slot of the stream
+                        ray_index = mine;
+                        if (tr.begin(S, o, d, tmax)) active = true;
+                        else io.done(ray_index, tr, false);
+                    }
+                }
+                const uint32_t taken = uint32_t(idle);
+                pool_next = (pool_end - pool_next < taken) ? pool_end : pool_next + taken;
+            } else if (exhausted && idle == kWave) {
+                break;
+            }
+        }
+        if (active) {
+            if (tr.step(S, stk, ev)) {
+                active = false;
+                io.done(ray_index, tr, MODE == MODE_ANY ? tr.found : tr.closest_valid());
+            }
+        }
+    }
+    io.flush();
 }
 
 }  // namespace ptd
