@@ -44,7 +44,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--capture-iters", type=int, default=8)
-    ap.add_argument("--spp-steps", type=int, default=16, help="render iterations per rank for the spp/s leg (0 = skip)")
+    ap.add_argument("--spp-steps", type=int, default=32, help="render iterations per rank for the spp/s leg (0 = skip)")
+    ap.add_argument("--spp-batch", type=int, default=8, help="iterations kept in flight per wavefront pass in the spp/s leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--rays", default="captured", choices=["captured", "synthetic"])
     args = ap.parse_args()
@@ -137,16 +138,18 @@ def main():
     spp = None
     if args.spp_steps > 0:
         film = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
-        for w_it in range(2):
-            ctx.render(W, H, w_it, 0, sync=False)
+        B = max(1, args.spp_batch)
+        passes = max(1, args.spp_steps // B)
+        args.spp_steps = passes * B
+        ctx.render_batch(W, H, 0, B)
         ctx.synchronize()
         ctx.integrator_reset(W, H)
         ctx.reset_stats()
         barrier()
         t0 = time.perf_counter()
-        for k in range(args.spp_steps):
-            iteration = rank + k * world
-            ctx.render(W, H, iteration if iteration > 0 else 0, 0, sync=False)
+        for k in range(passes):
+            # rank r owns the iteration blocks r, r+N, r+2N, ... of B consecutive iterations each
+            ctx.render_batch(W, H, (rank + k * world) * B, B)
         ctx.synchronize()
         ctx.film_copy_to_device(film.data_ptr())
         if distributed:
@@ -160,8 +163,8 @@ def main():
         st2 = ctx.stats()
         spp = {"spp_per_s": args.spp_steps * world / spp_elapsed, "ms_per_spp": spp_elapsed * 1e3 / (args.spp_steps * world),
                "mpaths_per_s": args.spp_steps * world * W * H / spp_elapsed / 1e6,
-               "rays_per_spp_last": {"closest": int(st2.closest_rays), "shadow": int(st2.shadow_rays)},
-               "iterations": args.spp_steps * world, "film_reduce": "rccl reduce(sum) to rank 0" if distributed else "none"}
+               "rays_last_pass": {"closest": int(st2.closest_rays), "shadow": int(st2.shadow_rays)},
+               "iterations": args.spp_steps * world, "samples_in_flight": B, "film_reduce": "rccl reduce(sum) to rank 0" if distributed else "none"}
 
     # ---- leg 3: CPU baseline (rank 0, N == 1 only): the oracle's traversal on a bounded sample
     cpu = None

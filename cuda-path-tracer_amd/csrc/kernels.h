@@ -11,6 +11,7 @@
 
 namespace ptd {
 
+constexpr int kStageCap = 128;  // per-class staging entries per wave: < 64 carried over + <= 64 new
 constexpr int kNumClasses = 5;  // 0 = emissive hit or miss, 1 lambertian, 2 mirror, 3 metallic-roughness, 4 dielectric
 
 // Per-bounce counters, 64 B, zeroed once per iteration for all bounces.
@@ -40,7 +41,8 @@ struct PathState {
     float4 *sh_c;      // contribution added when unoccluded
     uint32_t *ext_q[2];
     uint32_t *class_q[kNumClasses];
-    uint32_t capacity;  // path slots (pixels padded to 8x8 tiles)
+    uint32_t capacity;  // path slots = samples_in_flight * slots_per_sample
+    uint32_t slots_per_sample;  // pixels padded to 8x8 tiles
 };
 
 // One atomic per wave: lanes with `pred` receive consecutive slots of the queue behind `counter`.
@@ -95,6 +97,7 @@ struct ClosestIO {
         if (COUNT) counters[i] = tr.ctr;
     }
     PTD void flush() const {}
+    PTD void finish() const {}
 };
 
 template <bool COUNT>
@@ -122,6 +125,7 @@ struct AnyIO {
     }
     PTD void done(uint32_t i, const Traversal<MODE_ANY, false> &, bool hit) const { occluded[i] = hit ? 1 : 0; }
     PTD void flush() const {}
+    PTD void finish() const {}
 };
 
 __global__ __launch_bounds__(64) void k_trace_any(DScene S, const pt_ray *rays, uint32_t n, uint8_t *occluded, uint32_t *cursor,
@@ -200,9 +204,12 @@ __global__ void k_gen_incoherent(DScene S, pt_ray *rays, uint32_t n, uint64_t fi
 
 // ------------------------------------------------------------ path pipeline
 // Path slot <-> pixel: slots are laid out in 8x8 pixel tiles (one tile per wave) so that the
-// camera rays of a wave form a compact bundle.
+// camera rays of a wave form a compact bundle.  When several samples (iterations) are in flight
+// at once, sample k owns the slots [k * slots_per_sample, (k+1) * slots_per_sample).
 PTD bool slot_to_pixel(uint32_t slot, int width, int height, int &x, int &y) {
     const uint32_t tiles_x = uint32_t(width + 7) >> 3;
+    const uint32_t tiles_y = uint32_t(height + 7) >> 3;
+    slot %= tiles_x * tiles_y * 64u;
     const uint32_t tile = slot >> 6, within = slot & 63u;
     x = int((tile % tiles_x) * 8u + (within & 7u));
     y = int((tile / tiles_x) * 8u + (within >> 3));
@@ -210,11 +217,12 @@ PTD bool slot_to_pixel(uint32_t slot, int width, int height, int &x, int &y) {
 }
 
 // GenerateRaysKernel, path_trace.cu:76-108.
-__global__ __launch_bounds__(64) void k_generate(DScene S, PathState P, BounceCounters *cnt, int iteration, int width, int height) {
+__global__ __launch_bounds__(64) void k_generate(DScene S, PathState P, BounceCounters *cnt, int first_iteration, int width, int height) {
     const uint32_t slot = blockIdx.x * kWave + threadIdx.x;
     int x, y;
     const bool active = slot_to_pixel(slot, width, height, x, y);
     if (active) {
+        const int iteration = first_iteration + int(slot / P.slots_per_sample);
         uint64_t rng = seed_sampler(x, y, iteration);
         const float sx = sample1d(rng), sy = sample1d(rng);
         sample1d(rng);  // Sample4D draws four values; the lens pair is unused by the pinhole camera
@@ -282,15 +290,46 @@ struct ExtendIO {
         pend_slot = slot;
         pending = true;
     }
+    // Finished paths are staged per class in LDS and written out 64 at a time, so each class
+    // queue costs one atomic per 64 entries (same-address atomics serialise at ~12 ns each) and
+    // its stores are full 256-byte rows.
+    uint32_t *stage;                      // [kNumClasses][kStageCap], this wave's LDS staging area
+    uint32_t staged[kNumClasses] = {};    // wave-uniform fill levels
     PTD void flush() {
         if (__ballot(pending) == 0) return;
+        const uint32_t lane = threadIdx.x & 63;
 #pragma unroll
         for (int k = 0; k < kNumClasses; ++k) {
             const bool mine = pending && pend_cls == k;
-            const uint32_t q = wave_append(&bc->class_count[k], mine);
-            if (mine) P.class_q[k][q] = pend_slot;
+            const uint64_t mask = __ballot(mine);
+            if (mask == 0) continue;
+            const uint32_t prefix = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+            if (mine) stage[k * kStageCap + staged[k] + prefix] = pend_slot;
+            staged[k] += uint32_t(__popcll(mask));
+            if (staged[k] >= kWave) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&bc->class_count[k], uint32_t(kWave));
+                base = __shfl(base, 0, 64);
+                P.class_q[k][base + lane] = stage[k * kStageCap + lane];
+                const uint32_t rest = staged[k] - kWave;
+                const uint32_t moved = (lane < rest) ? stage[k * kStageCap + kWave + lane] : 0u;
+                if (lane < rest) stage[k * kStageCap + lane] = moved;
+                staged[k] = rest;
+            }
         }
         pending = false;
+    }
+    PTD void finish() {
+        const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+        for (int k = 0; k < kNumClasses; ++k) {
+            if (staged[k] == 0) continue;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&bc->class_count[k], staged[k]);
+            base = __shfl(base, 0, 64);
+            if (lane < staged[k]) P.class_q[k][base + lane] = stage[k * kStageCap + lane];
+            staged[k] = 0;
+        }
     }
 };
 
@@ -301,7 +340,9 @@ __global__ __launch_bounds__(64) void k_extend(DScene S, PathState P, BounceCoun
     const LaneStack stk{lds + lane, spill + size_t(blockIdx.x) * kWave + lane, spill_stride};
     BounceCounters *bc = cnt + bounce;
     LaneEvents ev;
+    __shared__ uint32_t stage[kNumClasses * kStageCap];
     ExtendIO io{S, P, bc, bounce == 0 ? nullptr : P.ext_q[bounce & 1], width, height};
+    io.stage = stage;
     trace_stream<MODE_CLOSEST, false>(S, io, bc->ext_count, &bc->cur_extend, stk, ev);
     flush_events(stats, ev);
 }
@@ -474,6 +515,7 @@ struct ShadowIO {
         P.accum[slot] = a;
     }
     PTD void flush() const {}
+    PTD void finish() const {}
 };
 
 __global__ __launch_bounds__(64) void k_shadow(DScene S, PathState P, BounceCounters *cnt, int bounce, uint2 *spill,
@@ -489,19 +531,27 @@ __global__ __launch_bounds__(64) void k_shadow(DScene S, PathState P, BounceCoun
 }
 
 // FinalGather, path_trace.cu:391-407: film += sample, NaN samples are dropped (and counted).
-__global__ __launch_bounds__(64) void k_film(PathState P, float *film, int width, int height, DevStats *stats) {
+// With several samples in flight the samples of a pixel are added in iteration order, which is
+// the order separate Render calls would add them, so the film is bit-identical either way.
+__global__ __launch_bounds__(64) void k_film(PathState P, float *film, int width, int height, int samples, DevStats *stats) {
     const uint32_t slot = blockIdx.x * kWave + threadIdx.x;
     int x, y;
     if (!slot_to_pixel(slot, width, height, x, y)) return;
-    float4 a = P.accum[slot];
-    if (isnan(a.x) || isnan(a.y) || isnan(a.z)) {
-        atomicAdd(&stats->nan_pixels, 1u);
-        a = make_float4(0, 0, 0, 0);
-    }
     float *px = film + 3 * (size_t(y) * width + x);
-    px[0] += a.x;
-    px[1] += a.y;
-    px[2] += a.z;
+    float r = px[0], g = px[1], b = px[2];
+    for (int k = 0; k < samples; ++k) {
+        float4 a = P.accum[size_t(k) * P.slots_per_sample + slot];
+        if (isnan(a.x) || isnan(a.y) || isnan(a.z)) {
+            atomicAdd(&stats->nan_pixels, 1u);
+            a = make_float4(0, 0, 0, 0);
+        }
+        r += a.x;
+        g += a.y;
+        b += a.z;
+    }
+    px[0] = r;
+    px[1] = g;
+    px[2] = b;
 }
 
 // PostprocessAndUpload, path_trace.cu:409-434: film / iterations -> ACES -> (int)(p * 255.0), no gamma.

@@ -50,12 +50,15 @@ struct pt_ctx {
     bool integrator_ready = false;
     int width = 0, height = 0;
     PathState paths;
-    std::vector<void *> path_allocs;
+    std::vector<void *> path_allocs;   // film, counters
+    std::vector<void *> state_allocs;  // per-path state and queues (re-sized with the batch)
+    uint32_t samples_alloc = 0;        // samples (iterations) the path state can hold in flight
     float *film = nullptr;
     BounceCounters *counters = nullptr;
     uint32_t counters_capacity = 0;  // bounces + 1
     uint32_t *pinned_word = nullptr;
     int last_render_bounces = 0;
+    int last_render_samples = 1;
 
     // profiling
     bool profiling = false;
@@ -426,7 +429,7 @@ int pt_get_stats(pt_ctx *ctx, pt_stats *out) {
         ctx->stats.bounces_run = 0;
         std::memset(ctx->stats.queue_sizes, 0, sizeof(ctx->stats.queue_sizes));
         // bounce 0 streams all path slots (8x8-tile padded); its real ray count is one per pixel
-        bc[0].ext_count = uint32_t(ctx->width) * uint32_t(ctx->height);
+        bc[0].ext_count = uint32_t(ctx->width) * uint32_t(ctx->height) * uint32_t(ctx->last_render_samples);
         for (int b = 0; b < ctx->last_render_bounces; ++b) {
             ctx->stats.closest_rays += bc[b].ext_count;
             ctx->stats.shadow_rays += bc[b].shadow_count;
@@ -709,11 +712,37 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
 }
 
 // ------------------------------------------------------------------ integrator
+// (Re)allocates the per-path state for `samples` iterations in flight at the context's resolution.
+static int EnsurePaths(pt_ctx *ctx, uint32_t samples) {
+    if (ctx->samples_alloc >= samples) return PT_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    FreeAll(ctx->state_allocs);
+    ctx->samples_alloc = 0;
+    const uint32_t tiles = uint32_t((ctx->width + 7) / 8) * uint32_t((ctx->height + 7) / 8);
+    const size_t per_sample = size_t(tiles) * 64;
+    const size_t cap = per_sample * samples;
+    if (cap >= (1ull << 31)) return Fail(ctx, PT_ERR_LIMIT, "%u samples in flight at %dx%d exceed 2^31 path slots", samples, ctx->width, ctx->height);
+    PathState &P = ctx->paths;
+    std::memset(&P, 0, sizeof(P));
+    int st = PT_OK;
+#define AL(field) if ((st = Alloc(ctx, ctx->state_allocs, cap, &P.field)) != PT_OK) return st
+    AL(ray_o); AL(ray_d); AL(thr); AL(accum); AL(last_pos); AL(rng); AL(hit); AL(hit_inst); AL(sh_o); AL(sh_d); AL(sh_c);
+    AL(ext_q[0]); AL(ext_q[1]);
+    for (int k = 0; k < kNumClasses; ++k) AL(class_q[k]);
+#undef AL
+    P.capacity = uint32_t(cap);
+    P.slots_per_sample = uint32_t(per_sample);
+    ctx->samples_alloc = samples;
+    return PT_OK;
+}
+
 int pt_integrator_destroy(pt_ctx *ctx) {
     if (!ctx) return PT_ERR_INVALID;
     DeviceGuard guard(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     FreeAll(ctx->path_allocs);
+    FreeAll(ctx->state_allocs);
+    ctx->samples_alloc = 0;
     ctx->film = nullptr;
     ctx->counters = nullptr;
     ctx->counters_capacity = 0;
@@ -731,19 +760,11 @@ int pt_integrator_init(pt_ctx *ctx, int width, int height) {
     pt_integrator_destroy(ctx);
     int st = EnsureScratch(ctx);
     if (st != PT_OK) return st;
-    const uint32_t tiles = uint32_t((width + 7) / 8) * uint32_t((height + 7) / 8);
-    const size_t cap = size_t(tiles) * 64;
-    PathState &P = ctx->paths;
-    P.capacity = uint32_t(cap);
-#define AL(field) if ((st = Alloc(ctx, ctx->path_allocs, cap, &P.field)) != PT_OK) return st
-    AL(ray_o); AL(ray_d); AL(thr); AL(accum); AL(last_pos); AL(rng); AL(hit); AL(hit_inst); AL(sh_o); AL(sh_d); AL(sh_c);
-    AL(ext_q[0]); AL(ext_q[1]);
-    for (int k = 0; k < kNumClasses; ++k) AL(class_q[k]);
-#undef AL
     if ((st = Alloc(ctx, ctx->path_allocs, size_t(width) * height * 3, &ctx->film)) != PT_OK) return st;
     HIP_TRY(ctx, hipMemsetAsync(ctx->film, 0, size_t(width) * height * 3 * sizeof(float), ctx->stream));
     ctx->width = width;
     ctx->height = height;
+    if ((st = EnsurePaths(ctx, 1)) != PT_OK) return st;
     ctx->integrator_ready = true;
     return PT_OK;
 }
@@ -770,13 +791,15 @@ static int EnsureCounters(pt_ctx *ctx, uint32_t bounces) {
 }
 
 // Runs generate + `bounces` bounce rounds of iteration `iteration` (no film pass).
-static int RunBounces(pt_ctx *ctx, int width, int height, int iteration, int bounces, bool shade_last) {
+static int RunBounces(pt_ctx *ctx, int width, int height, int iteration, int samples, int bounces, bool shade_last) {
     const DScene &S = ctx->scene;
+    int st = EnsurePaths(ctx, uint32_t(samples));
+    if (st != PT_OK) return st;
     PathState &P = ctx->paths;
-    int st = EnsureCounters(ctx, S.max_depth);
+    st = EnsureCounters(ctx, S.max_depth);
     if (st != PT_OK) return st;
     HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, size_t(ctx->counters_capacity) * sizeof(BounceCounters), ctx->stream));
-    const uint32_t tiles = P.capacity / 64;
+    const uint32_t tiles = P.slots_per_sample / 64 * uint32_t(samples);
     {
         ScopedEvent ev(ctx, EV_GENERATE);
         hipLaunchKernelGGL(k_generate, dim3(tiles), dim3(kWave), 0, ctx->stream, S, P, ctx->counters, iteration, width, height);
@@ -812,8 +835,9 @@ static int RunBounces(pt_ctx *ctx, int width, int height, int iteration, int bou
     return PT_OK;
 }
 
-int pt_render_async(pt_ctx *ctx, int width, int height, int iteration, uint8_t *rgba_device) {
+int pt_render_batch(pt_ctx *ctx, int width, int height, int iteration, int samples, uint8_t *rgba_device) {
     if (!ctx) return PT_ERR_INVALID;
+    if (samples < 1 || samples > 1024) return Fail(ctx, PT_ERR_LIMIT, "samples per pass must be in [1, 1024]");
     if (!ctx->scene_ready) return Fail(ctx, PT_ERR_STATE, "pt_render before pt_scene_upload");
     if (!ctx->integrator_ready) return Fail(ctx, PT_ERR_STATE, "pt_render before pt_integrator_init");
     if (width != ctx->width || height != ctx->height) return Fail(ctx, PT_ERR_INVALID, "render resolution %dx%d differs from the integrator's %dx%d", width, height, ctx->width, ctx->height);
@@ -822,18 +846,24 @@ int pt_render_async(pt_ctx *ctx, int width, int height, int iteration, uint8_t *
     if (iteration < 0) return Fail(ctx, PT_ERR_INVALID, "iteration must be >= 0");
     DeviceGuard guard(ctx->device);
     if (iteration == 0) HIP_TRY(ctx, hipMemsetAsync(ctx->film, 0, size_t(width) * height * 3 * sizeof(float), ctx->stream));  // path_trace.cu:438-439
-    int st = RunBounces(ctx, width, height, iteration, int(ctx->scene.max_depth), true);
+    int st = RunBounces(ctx, width, height, iteration, samples, int(ctx->scene.max_depth), true);
     if (st != PT_OK) return st;
     {
         ScopedEvent ev(ctx, EV_FILM);
-        hipLaunchKernelGGL(k_film, dim3(ctx->paths.capacity / 64), dim3(kWave), 0, ctx->stream, ctx->paths, ctx->film, width, height, ctx->dev_stats);
+        hipLaunchKernelGGL(k_film, dim3(ctx->paths.slots_per_sample / 64), dim3(kWave), 0, ctx->stream, ctx->paths, ctx->film, width, height, samples,
+                           ctx->dev_stats);
     }
     if (rgba_device) {
         const uint32_t n = uint32_t(width) * uint32_t(height);
-        hipLaunchKernelGGL(k_tonemap, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->film, rgba_device, width, height, iteration + 1);
+        hipLaunchKernelGGL(k_tonemap, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->film, rgba_device, width, height, iteration + samples);
     }
     HIP_TRY(ctx, hipGetLastError());
+    ctx->last_render_samples = samples;
     return PT_OK;
+}
+
+int pt_render_async(pt_ctx *ctx, int width, int height, int iteration, uint8_t *rgba_device) {
+    return pt_render_batch(ctx, width, height, iteration, 1, rgba_device);
 }
 
 int pt_render(pt_ctx *ctx, int width, int height, int iteration, uint8_t *rgba_device) {
@@ -1023,7 +1053,8 @@ int pt_capture_bounce_rays(pt_ctx *ctx, int width, int height, int iteration, in
     if (bounce < 0 || uint32_t(bounce) >= ctx->scene.max_depth) return Fail(ctx, PT_ERR_INVALID, "bounce %d outside [0, max_depth)", bounce);
     if (!rays_device || (reinterpret_cast<uintptr_t>(rays_device) & 15u)) return Fail(ctx, PT_ERR_INVALID, "ray buffer must be a 16-byte aligned device pointer");
     DeviceGuard guard(ctx->device);
-    int st = RunBounces(ctx, width, height, iteration, bounce + 1, false);
+    int st = RunBounces(ctx, width, height, iteration, 1, bounce + 1, false);
+    ctx->last_render_samples = 1;
     if (st != PT_OK) return st;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned_word, &ctx->counters[bounce].ext_count, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

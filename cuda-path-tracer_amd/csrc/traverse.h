@@ -325,7 +325,8 @@ struct Traversal {
 // are idle, so the reload code runs for a meaningful share of the wave).
 //   io.load(i, o, d, tmax)              ray i of the stream
 //   io.done(i, trav, valid)             called once per ray by the lane that traced it
-//   io.flush(pending)                   called by all 64 lanes at every refill point
+//   io.flush()                          called by all 64 lanes at every refill point
+//   io.finish()                         called by all 64 lanes once, after the last flush
 constexpr uint32_t kFetchChunk = 256;
 constexpr int kRefillMin = 16;
 
@@ -379,6 +380,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, con
         }
     }
     io.flush();
+    io.finish();
 }
 
 }  // namespace ptd

@@ -348,6 +348,10 @@ class Context:
         fn = self._lib.pt_render if sync else self._lib.pt_render_async
         self._check(fn(self._h, w, h, iteration, C.c_void_p(rgba_device_ptr)))
 
+    def render_batch(self, w, h, iteration, samples, rgba_device_ptr: int = 0):
+        """`samples` iterations in one wavefront pass (asynchronous); film identical to separate renders."""
+        self._check(self._lib.pt_render_batch(self._h, w, h, iteration, samples, C.c_void_p(rgba_device_ptr)))
+
     def film_download(self, w, h) -> np.ndarray:
         out = np.zeros((h, w, 3), np.float32)
         self._check(self._lib.pt_film_download(self._h, abi.vptr(out)))

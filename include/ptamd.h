@@ -284,6 +284,14 @@ int pt_render(pt_ctx *ctx, int width, int height, int iteration, uint8_t *rgba_d
 /* Same, without the trailing host synchronisation (for back-to-back samples). */
 int pt_render_async(pt_ctx *ctx, int width, int height, int iteration, uint8_t *rgba_device);
 
+/* `samples` consecutive iterations (iteration .. iteration+samples-1) in ONE wavefront pass:
+ * all their paths are in flight together, so every launch carries `samples` times the work
+ * (path state grows to samples * W*H slots; MI355X's HBM is sized for that).  The film receives
+ * the samples of a pixel in iteration order, so the result is bit-identical to `samples` calls
+ * of pt_render.  Asynchronous like pt_render_async.  No counterpart in the reference, whose
+ * Render traces one sample per call.                                                         */
+int pt_render_batch(pt_ctx *ctx, int width, int height, int iteration, int samples, uint8_t *rgba_device);
+
 /* Film access (the reference keeps m_image private; the headless path and the
  * multi-GPU reduce need it). rgb = W*H*3 fp32, row-major.                     */
 int pt_film_download(pt_ctx *ctx, float *rgb_host);

@@ -206,3 +206,24 @@ def test_deep_path_limit_terminates_early(pt, gpu_ctx, scene_factory):
     st = gpu_ctx.stats()
     assert 3 < st.bounces_run < 100
     assert np.isfinite(gpu_ctx.film_download(w, h)).all()
+
+
+def test_batched_samples_equal_separate_renders(pt, gpu_ctx, scene_factory):
+    """pt_render_batch keeps several iterations in flight in one wavefront pass; the film must
+    be bit-identical to rendering the same iterations one call at a time."""
+    w, h = 96, 72
+    hs = scene_factory("teapot", w, h, 6)
+    gpu_ctx.upload(hs.desc())
+    gpu_ctx.integrator_init(w, h)
+    for it in range(7):
+        gpu_ctx.render(w, h, it)
+    single = gpu_ctx.film_download(w, h)
+    gpu_ctx.render_batch(w, h, 0, 4)
+    gpu_ctx.render_batch(w, h, 4, 3)
+    gpu_ctx.synchronize()
+    batched = gpu_ctx.film_download(w, h)
+    assert np.array_equal(single.view(np.uint32), batched.view(np.uint32))
+    st = gpu_ctx.stats()
+    assert st.paths == 3 * w * h
+    with pytest.raises(pt.PtError, match="samples per pass"):
+        gpu_ctx.render_batch(w, h, 0, 0)
