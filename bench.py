@@ -180,11 +180,25 @@ def main():
         ora.trace_closest(desc, probe, nthreads=threads)
         rate = len(probe) / max(time.perf_counter() - t0, 1e-6)
         sample = rays_h[: int(min(len(rays_h), max(len(probe), rate * args.cpu_seconds)))]
+        repeats = int(max(1, min(64, round(rate * args.cpu_seconds / len(sample)))))
         t0 = time.perf_counter()
-        ora.trace_closest(desc, sample, nthreads=threads)
+        for _ in range(repeats):
+            ora.trace_closest(desc, sample, nthreads=threads)
         cpu_t = time.perf_counter() - t0
-        cpu = {"value": len(sample) / cpu_t / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-               "sample": f"first {len(sample)} rays of the same batch, oracle/liboracle.so ora_trace_closest, {threads} threads, {cpu_t:.1f} s"}
+        cpu = {"value": len(sample) * repeats / cpu_t / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+               "sample": f"first {len(sample)} rays of the same batch traced {repeats}x, oracle/liboracle.so ora_trace_closest, "
+                         f"{threads} threads, {cpu_t:.1f} s"}
+
+    # HBM-side bytes per launch from the committed PMC passes (counters cannot be read in-process);
+    # only quoted when the profile was taken on this same batch
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            rec = json.load(f)["k_trace_closest"]
+        if abs(rec["rays"] - n_rays) <= 0.01 * n_rays and args.rays == "captured":
+            traffic = rec["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        traffic = None
 
     if rank == 0:
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
@@ -195,7 +209,7 @@ def main():
             "config": {"workload": workload, "rays_per_rank": n_rays, "scene": args.scene, "resolution": [W, H], "max_depth": depth,
                        "parallelism": f"rays sharded over {world} rank(s), scene replicated"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_trace_closest", "kernel_ms": kernel_ms, "launches": int(st.n_closest),
+                         "traffic": traffic, "kernel": "k_trace_closest", "kernel_ms": kernel_ms, "launches": int(st.n_closest),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "visits_per_ray": {"interior": csum[0] / n_rays, "tlas_leaves": csum[1] / n_rays, "triangles": csum[2] / n_rays}},
             "cpu_baseline": cpu,
