@@ -123,10 +123,8 @@ def main():
     ctx.set_profiling(False)
     st = ctx.stats()
     kernel_ms = st.ms_closest / max(1, st.n_closest)
+    elapsed = pt.sharding.max_over_ranks(elapsed, dev)
     if distributed:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
         nr = torch.tensor([n_rays], dtype=torch.int64, device=dev)
         dist.all_reduce(nr, op=dist.ReduceOp.SUM)
         total_rays = int(nr.item())
@@ -147,19 +145,14 @@ def main():
         ctx.reset_stats()
         barrier()
         t0 = time.perf_counter()
-        for k in range(passes):
-            # rank r owns the iteration blocks r, r+N, r+2N, ... of B consecutive iterations each
-            ctx.render_batch(W, H, (rank + k * world) * B, B)
+        # rank r owns the iteration blocks r, r+N, r+2N, ... of B consecutive iterations each
+        for first, count in pt.sharding.iteration_blocks(rank, world, args.spp_steps * world, B):
+            ctx.render_batch(W, H, first, count)
         ctx.synchronize()
         ctx.film_copy_to_device(film.data_ptr())
-        if distributed:
-            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
+        pt.sharding.reduce_film(film, dst=0)
         barrier()
-        spp_elapsed = time.perf_counter() - t0
-        if distributed:
-            tt = torch.tensor([spp_elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            spp_elapsed = float(tt.item())
+        spp_elapsed = pt.sharding.max_over_ranks(time.perf_counter() - t0, dev)
         st2 = ctx.stats()
         spp = {"spp_per_s": args.spp_steps * world / spp_elapsed, "ms_per_spp": spp_elapsed * 1e3 / (args.spp_steps * world),
                "mpaths_per_s": args.spp_steps * world * W * H / spp_elapsed / 1e6,

@@ -182,11 +182,13 @@ __global__ void k_resolve_hits(DScene S, const pt_ray *rays, const pt_hit *hits,
 }
 
 // Incoherent rays: origin uniform in the root box scaled 1.1x about its centre, direction
-// uniform on the sphere, PCG state (i << 32) | 0xdeadbeef.
+// uniform on the sphere, PCG state (i << 32) | 0xdeadbeef after two discarded draws.
 __global__ void k_gen_incoherent(DScene S, pt_ray *rays, uint32_t n, uint64_t first_index) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     uint64_t rng = ((first_index + k) << 32) | 0xdeadbeefull;
+    sample1d(rng);  // the outputs of an unmixed counter state are ~0: two LCG steps mix it first
+    sample1d(rng);
     float o[3];
     for (int a = 0; a < 3; ++a) {
         const float c = 0.5f * (S.root_min[a] + S.root_max[a]);

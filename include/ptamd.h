@@ -234,6 +234,26 @@ typedef struct pt_stats {
     uint32_t n_closest, n_any, n_generate, n_shade, n_film;    /* launches    */
 } pt_stats;
 
+/* The record sizes the reference's host vectors have; a reinterpret_cast of
+ * those vectors is only valid while these hold.                              */
+#ifdef __cplusplus
+#define PT_SIZE_CHECK(type, bytes) static_assert(sizeof(type) == (bytes), #type " layout")
+#else
+#define PT_SIZE_CHECK(type, bytes) _Static_assert(sizeof(type) == (bytes), #type " layout")
+#endif
+PT_SIZE_CHECK(pt_bvh_node, 32);
+PT_SIZE_CHECK(pt_tlas_node, 32);
+PT_SIZE_CHECK(pt_blas, 16);
+PT_SIZE_CHECK(pt_geometry_instance, 224);
+PT_SIZE_CHECK(pt_material, 16);
+PT_SIZE_CHECK(pt_texture1, 32);
+PT_SIZE_CHECK(pt_texture3, 44);
+PT_SIZE_CHECK(pt_area_light, 8);
+PT_SIZE_CHECK(pt_ray, 32);
+PT_SIZE_CHECK(pt_hit, 32);
+PT_SIZE_CHECK(pt_intersection, 44);
+#undef PT_SIZE_CHECK
+
 typedef struct pt_ctx pt_ctx;
 
 /* ---------------------------------------------------------------- lifecycle */
@@ -327,7 +347,7 @@ int pt_resolve_hits_host(pt_ctx *ctx, const pt_ray *rays, const pt_hit *hits, si
 /* Fills n incoherent rays on the device: origin uniform in the scene's root
  * box scaled 1.1x about its centre, direction uniform on the sphere, tmax
  * FLT_MAX, drawn from the per-ray PCG stream state = (i << 32) | 0xdeadbeef
- * (i = first_index + ray number).                                             */
+ * (i = first_index + ray number) after two discarded draws.                  */
 int pt_generate_incoherent_rays(pt_ctx *ctx, pt_ray *rays_device, size_t n, uint64_t first_index);
 /* Captures the extension-ray queue of `bounce` (0 = camera rays) of `iteration`
  * into rays_device (capacity rays); *count receives the number written.       */

@@ -1638,12 +1638,15 @@ int ora_trace_naive(const pt_scene_desc *desc, const pt_ray *rays, size_t n, pt_
 
 // Incoherent ray set: origin uniform in the TLAS root box scaled 1.1x about its centre,
 // direction uniform on the sphere (z = 1-2*xi1, phi = 2*pi*xi2), drawn from the PCG
-// stream of kernel/sampler/independent.h:25-32 with state = (i << 32) | 0xdeadbeef.
+// stream of kernel/sampler/independent.h:25-32 with state = (i << 32) | 0xdeadbeef after two
+// discarded draws.
 void ora_generate_incoherent_rays(const pt_scene_desc *desc, pt_ray *rays, size_t n, uint64_t first_index) {
     const pt_tlas_node &root = desc->tlas_nodes[0];
     for (size_t k = 0; k < n; ++k) {
         Sampler s;
         s.state = ((first_index + k) << 32) | 0xdeadbeefull;
+        Sample1D(s);  // the outputs of an unmixed counter state are ~0: two LCG steps mix it first
+        Sample1D(s);
         float o[3];
         for (int a = 0; a < 3; ++a) {
             float c = 0.5f * (root.min[a] + root.max[a]);

@@ -49,6 +49,10 @@ def scene_factory(pt):
 
 @pytest.fixture(scope="session")
 def tiny_scene(pt):
+    return make_tiny_scene(pt)
+
+
+def make_tiny_scene(pt):
     """Hand-made scene: a lit quad light above a floor quad, a tilted cube and an instanced,
     non-uniformly scaled copy of it; one material of every kind; checkerboard floor."""
     hs = pt.HostScene()
