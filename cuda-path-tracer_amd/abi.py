@@ -144,9 +144,10 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("PTAMD_LIB", LIB_PATH)  # diagnostic builds (tools/) live beside the product library
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: the HIP extension has not been built. "
+            f"{path} is missing: the HIP extension has not been built. "
             "Run `python -c \"import __graft_entry__ as g; g.build()\"` (needs hipcc); there is no CPU fallback.")
     # One process must hold ONE HIP/HSA runtime: PyTorch-ROCm bundles its own libamdhip64.so, and
     # whichever runtime initialises second finds no device.  Importing torch first makes the
@@ -155,7 +156,7 @@ def load_library() -> C.CDLL:
         import torch  # noqa: F401
     except ImportError:
         pass
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     vp, i32, u32, u64, f32 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_float
     fp = C.POINTER(C.c_float)
     up = C.POINTER(C.c_uint32)

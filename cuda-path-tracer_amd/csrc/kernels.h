@@ -8,6 +8,7 @@
 // MaterialShadeKernel<M>, EmissiveHitKernel, FinalGather, PostprocessAndUpload).
 #pragma once
 #include "shade.h"
+#include "stream.h"
 
 namespace ptd {
 
@@ -65,9 +66,19 @@ PTD uint32_t wave_fetch(uint32_t *cursor, uint32_t amount) {
     return __shfl(v, 0, 64);
 }
 
+#ifdef PT_PHASE_PROF
+__device__ unsigned long long g_phase_prof[16];
+#endif
+
 PTD void flush_events(DevStats *stats, const LaneEvents &ev) {
     if (ev.spills) atomicAdd(&stats->spills, ev.spills);
     if (ev.drops) atomicAdd(&stats->drops, ev.drops);
+#ifdef PT_PHASE_PROF
+    for (int k = 0; k < 8; ++k) {
+        if (ev.lane_rounds[k]) atomicAdd(&g_phase_prof[k], (unsigned long long)ev.lane_rounds[k]);
+        if (ev.wave_rounds[k]) atomicAdd(&g_phase_prof[8 + k], (unsigned long long)ev.wave_rounds[k]);
+    }
+#endif
 }
 
 // ------------------------------------------------------------- batch queries
@@ -103,9 +114,9 @@ struct ClosestIO {
 template <bool COUNT>
 __global__ __launch_bounds__(64) void k_trace_closest(DScene S, const pt_ray *rays, uint32_t n, pt_hit *hits, uint32_t *cursor,
                                                       uint2 *spill, uint32_t spill_stride, DevStats *stats, TraceCounters *counters) {
-    __shared__ uint2 lds[kLdsDepth * kWave];
+    __shared__ unsigned long long lds[kLdsDepth * kWave];
     const uint32_t lane = threadIdx.x;
-    const LaneStack stk{lds + lane, spill + size_t(blockIdx.x) * kWave + lane, spill_stride};
+    const LaneStack stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
     LaneEvents ev;
     ClosestIO<COUNT> io{S, rays, hits, counters};
     trace_stream<MODE_CLOSEST, COUNT>(S, io, n, cursor, stk, ev);
@@ -130,9 +141,9 @@ struct AnyIO {
 
 __global__ __launch_bounds__(64) void k_trace_any(DScene S, const pt_ray *rays, uint32_t n, uint8_t *occluded, uint32_t *cursor,
                                                   uint2 *spill, uint32_t spill_stride, DevStats *stats) {
-    __shared__ uint2 lds[kLdsDepth * kWave];
+    __shared__ unsigned long long lds[kLdsDepth * kWave];
     const uint32_t lane = threadIdx.x;
-    const LaneStack stk{lds + lane, spill + size_t(blockIdx.x) * kWave + lane, spill_stride};
+    const LaneStack stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
     LaneEvents ev;
     AnyIO io{rays, occluded};
     trace_stream<MODE_ANY, false>(S, io, n, cursor, stk, ev);
@@ -337,9 +348,9 @@ struct ExtendIO {
 
 __global__ __launch_bounds__(64) void k_extend(DScene S, PathState P, BounceCounters *cnt, int bounce, int width, int height, uint2 *spill,
                                                uint32_t spill_stride, DevStats *stats) {
-    __shared__ uint2 lds[kLdsDepth * kWave];
+    __shared__ unsigned long long lds[kLdsDepth * kWave];
     const uint32_t lane = threadIdx.x;
-    const LaneStack stk{lds + lane, spill + size_t(blockIdx.x) * kWave + lane, spill_stride};
+    const LaneStack stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
     BounceCounters *bc = cnt + bounce;
     LaneEvents ev;
     __shared__ uint32_t stage[kNumClasses * kStageCap];
@@ -522,9 +533,9 @@ struct ShadowIO {
 
 __global__ __launch_bounds__(64) void k_shadow(DScene S, PathState P, BounceCounters *cnt, int bounce, uint2 *spill,
                                                uint32_t spill_stride, DevStats *stats) {
-    __shared__ uint2 lds[kLdsDepth * kWave];
+    __shared__ unsigned long long lds[kLdsDepth * kWave];
     const uint32_t lane = threadIdx.x;
-    const LaneStack stk{lds + lane, spill + size_t(blockIdx.x) * kWave + lane, spill_stride};
+    const LaneStack stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
     BounceCounters *bc = cnt + bounce;
     LaneEvents ev;
     ShadowIO io{P};

@@ -12,6 +12,9 @@
 
 #include "../../include/ptamd.h"
 #include "kernels.h"
+#ifndef PT_WAVES_PER_CU
+#define PT_WAVES_PER_CU 16  // persistent waves per CU (4 per SIMD)
+#endif
 
 using namespace ptd;
 
@@ -340,7 +343,8 @@ int pt_ctx_create(int device, pt_ctx **out) {
     }
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     // one wave per block; LDS stack = kLdsDepth*64*8 B per wave -> 160 KiB / 12 KiB = 13 waves per CU
-    const int waves_per_cu = std::min(16, int((160 * 1024) / (kLdsDepth * kWave * sizeof(uint2))));
+    int waves_per_cu = std::min(PT_WAVES_PER_CU, int((160 * 1024) / (kLdsDepth * kWave * sizeof(uint2))));
+    if (const char *e = getenv("PTAMD_WAVES_PER_CU")) waves_per_cu = std::max(1, std::min(32, atoi(e)));  // tuning aid
     ctx->grid_blocks = uint32_t(ctx->num_cus * waves_per_cu);
     e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -391,6 +395,16 @@ int pt_set_profiling(pt_ctx *ctx, int enabled) {
     ctx->profiling = enabled != 0;
     return PT_OK;
 }
+
+#ifdef PT_PHASE_PROF
+// Diagnostic build only: reads and clears the phase counters of the traversal loop.
+int pt_debug_phase_prof(unsigned long long *out16) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ptd::g_phase_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return PT_ERR_DEVICE;
+    unsigned long long zero[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_phase_prof), zero, sizeof(zero)) != hipSuccess) return PT_ERR_DEVICE;
+    return PT_OK;
+}
+#endif
 
 int pt_set_trace_mode(pt_ctx *ctx, int mode) {
     if (!ctx) return PT_ERR_INVALID;
@@ -675,6 +689,7 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
 
 #define UP(field, vec)                                                                             \
     if ((st = Upload(ctx, ctx->scene_allocs, (vec).data(), (vec).size(), &S.field)) != PT_OK) return st
+    if (nodes.empty()) nodes.emplace_back();  // lanes without work read record 0 of this array
     UP(nodes, nodes);
     UP(tris, tris);
     UP(insts, insts);

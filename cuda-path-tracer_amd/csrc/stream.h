@@ -1,0 +1,378 @@
+// Per-lane traversal state and the wave-level scheduler that streams rays through it.
+//
+// A busy lane is always in one of four situations:
+//   wants_interior()  cur is an interior node: test its two child boxes
+//   wants_triangle()  cur is a BLAS leaf: test the next triangle of it
+//   wants_enter()     cur is a TLAS leaf: move the ray into the instance's space
+//   wants_level()     cur is empty and the current level's stack ran dry: leave the instance
+//                     (weighing its candidate hit against the best so far) or finish the ray
+// plus the cheap case "cur is empty, the stack is not": pop.
+//
+// Running every code path for every lane on every round leaves most VALU lanes masked off
+// (measured on bounce rays: 26 % of the lanes busy in the box tests).  So the wave counts the
+// lanes that want each operation and runs an operation only while enough lanes want it; the
+// others wait.  The box-test loop, by far the most frequent operation, holds nothing but the
+// node fetch, the pop and the two slab tests; everything that changes the level of the
+// traversal happens outside it.  Each lane still performs its own operations in the
+// reference's order, so the results do not depend on the schedule.
+#pragma once
+#include "traverse.h"
+
+namespace ptd {
+
+template <int MODE, bool COUNT>
+struct Traversal {
+    V3 o, d, iw;     // world-space ray and reciprocal direction
+    V3 co, cd, ci;   // ray in the current space (world, or the current instance's object space)
+    float t_max;
+    float best;      // best world-space distance over finished instances
+    float cbest;     // culling bound of the current level: `best` in the TLAS, the instance's own
+                     // best object-space distance inside a BLAS; the ray's t_max in MODE_ANY
+    uint32_t lrec;
+    float lu, lv;
+    int cur_inst;
+    int sp, base;
+    bool in_blas;
+    uint32_t cur;
+    uint32_t tri_next, tri_left;  // progress inside the current BLAS leaf (tri_left == 0: not opened)
+    HitRec hit;
+    bool found;      // MODE_ANY: an occluder was found
+    TraceCounters ctr;
+
+    // Returns false when the ray misses the scene's root box (kernel/intersection.h:162).
+    PTD bool begin(const DScene &S, V3 origin, V3 dir, float tmax) {
+        o = origin;
+        d = dir;
+        t_max = tmax;
+        hit.t = -1.0f;
+        hit.u = hit.v = 0.0f;
+        hit.rec = 0;
+        hit.inst = -1;
+        found = false;
+        if (COUNT) ctr = TraceCounters{0, 0, 0, 0};
+        iw = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        float t;
+        if (!slab(o, iw, S.root_min[0], S.root_min[1], S.root_min[2], S.root_max[0], S.root_max[1], S.root_max[2], t_max, t)) return false;
+        co = o;
+        cd = d;
+        ci = iw;
+        best = FLT_MAX;
+        cbest = (MODE == MODE_ANY) ? t_max : FLT_MAX;
+        lrec = 0;
+        lu = lv = 0.0f;
+        cur_inst = -1;
+        sp = 0;
+        base = 0;
+        in_blas = false;
+        cur = S.root_ref;
+        tri_next = tri_left = 0;
+        return true;
+    }
+
+    // True when a closest hit exists (valid once finished; kernel/intersection.h:229-232).
+    PTD bool closest_valid() const { return !(best < 0.0f || best == FLT_MAX); }
+
+    PTD bool wants_interior() const { return cur < kNoRef; }
+    PTD bool wants_triangle() const { return cur > kNoRef && in_blas; }
+    PTD bool wants_enter() const { return cur > kNoRef && !in_blas; }
+    PTD bool wants_pop() const { return cur == kNoRef && sp != base && sp <= kLdsDepth; }
+    PTD bool wants_deep_pop() const { return cur == kNoRef && sp != base && sp > kLdsDepth; }  // entry is in the global spill area
+    PTD bool wants_level() const { return cur == kNoRef && sp == base; }
+
+    // One pop (kernel/intersection.h:54-60): the entry is dropped when its box starts beyond
+    // the current bound; then cur stays empty and the lane pops again next round.
+    // pop() only touches LDS, so the box-test loop never waits for a global load in it.
+    PTD void pop(const LaneStack &stk) {
+        --sp;
+        const unsigned long long v = stk.lds[sp * kWave];
+        if (MODE == MODE_ANY || as_f(uint32_t(v >> 32)) < cbest) cur = uint32_t(v);
+    }
+    PTD void deep_pop(const LaneStack &stk) {
+        --sp;
+        const uint2 e = stack_load(stk, sp);
+        if (MODE == MODE_ANY || as_f(e.y) < cbest) cur = e.x;
+    }
+
+    // One interior node: both child boxes, near child next, far child pushed
+    // (kernel/intersection.h:114-135, :203-226).
+    PTD void op_interior(const LaneStack &stk, LaneEvents &ev, float4 na, float4 nb, float4 nc, float4 nd) {
+        if (COUNT) ctr.interior++;
+        float tl, tr;
+        const bool hl = slab(co, ci, na.x, na.y, na.z, nb.x, nb.y, nb.z, cbest, tl);
+        const bool hr = slab(co, ci, nc.x, nc.y, nc.z, nd.x, nd.y, nd.z, cbest, tr);
+        const uint32_t lref = as_u(na.w), rref = as_u(nb.w);
+        const int depth = sp - base;
+        const bool both = hl && hr;
+        const bool left_first = tl < tr;
+        if (__builtin_expect(depth < kRefStack - 1, 1)) {
+            if (both) {
+                stack_store(stk, sp, left_first ? rref : lref, left_first ? tr : tl, ev);
+                ++sp;
+                cur = left_first ? lref : rref;
+            } else {
+                cur = hl ? lref : (hr ? rref : kNoRef);
+            }
+        } else {
+            // the reference's 64-entry stack is (nearly) full: reproduce which pushes it drops
+            // (utils/stack.h:8-11; it pushes the far child, then the near one, then pops)
+            if (both) {
+                if (depth == kRefStack - 1) {
+                    stack_store(stk, sp, left_first ? rref : lref, left_first ? tr : tl, ev);
+                    ++sp;
+                    ev.drops++;
+                } else {
+                    ev.drops += 2;
+                }
+                cur = kNoRef;
+            } else if (hl || hr) {
+                if (depth < kRefStack) {
+                    cur = hl ? lref : rref;
+                } else {
+                    ev.drops++;
+                    cur = kNoRef;
+                }
+            } else {
+                cur = kNoRef;
+            }
+        }
+    }
+
+    // TLAS leaf: enter the instance (kernel/intersection.h:183-188, :37-50).
+    PTD void op_enter(const DScene &S) {
+        if (COUNT) ctr.tlas_leaves++;
+        cur_inst = int(cur & 0x7FFFFFFFu);
+        const float4 *ip = reinterpret_cast<const float4 *>(S.insts + cur_inst);
+        DInst in;
+        in.a = ip[0];
+        in.b = ip[1];
+        in.c = ip[2];
+        in.d = ip[3];
+        const M34 inv = load_inv(in);
+        co = xform(inv, o, 1.0f);
+        cd = xform(inv, d, 0.0f);
+        ci = mk3(1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z);
+        if (MODE == MODE_CLOSEST) cbest = FLT_MAX;
+        base = sp;
+        in_blas = true;
+        cur = as_u(in.d.x);
+        tri_left = 0;
+    }
+
+    // The next triangle of the current leaf (kernel/intersection.h:63-112).  Returns true in
+    // MODE_ANY when the ray is occluded (finished).
+    PTD bool op_triangle(const DScene &S) {
+        if (tri_left == 0) {  // first visit: open the leaf
+            if (COUNT) ctr.blas_leaves++;
+            tri_next = cur & 0x0FFFFFFFu;
+            tri_left = ((cur >> 28) & 7u) + 1u;
+            if (tri_left == 8u) {
+                const uint2 big = S.big_leaves[tri_next];
+                tri_next = big.x;
+                tri_left = big.y;
+            }
+        }
+        if (COUNT) ctr.tris++;
+        const float4 *tp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(S.tris) + size_t(tri_next * uint32_t(sizeof(DTri))));
+        const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+        float t, u, v;
+        const bool ok = tri_test(co, cd, ta, tb, tc, t_max, t, u, v);
+        if (MODE == MODE_ANY) {
+            if (ok) {
+                found = true;
+                return true;
+            }
+        } else if (ok && t < cbest) {
+            cbest = t;
+            lrec = tri_next;
+            lu = u;
+            lv = v;
+        }
+        ++tri_next;
+        if (--tri_left == 0) cur = kNoRef;
+        return false;
+    }
+
+    // The current level has run dry.  Inside an instance: its candidate, if any, competes by
+    // world-space distance with the best of the other instances, and the ray returns to the
+    // TLAS (kernel/intersection.h:139-149, :190-194).  In the TLAS: the ray is finished.
+    // Returns true when finished.
+    PTD bool op_level(const DScene &S) {
+        if (in_blas) {
+            if (MODE == MODE_CLOSEST) {
+                if (cbest < FLT_MAX) {
+                    const V3 lp = tri_point(S.tris, lrec, lu, lv);
+                    const float4 *fp = reinterpret_cast<const float4 *>(S.fwd + cur_inst);
+                    const M34 T = load_m34(fp[0], fp[1], fp[2]);
+                    const V3 wp = xform(T, lp, 1.0f);
+                    const float wt = dot(wp - o, d);
+                    if (wt < best) {
+                        best = wt;
+                        hit.t = wt;
+                        hit.u = lu;
+                        hit.v = lv;
+                        hit.rec = lrec;
+                        hit.inst = cur_inst;
+                    }
+                }
+                cbest = best;
+            }
+            in_blas = false;
+            co = o;
+            cd = d;
+            ci = iw;
+            base = 0;
+        }
+        return sp == 0;
+    }
+};
+
+// Streams `n` rays through a persistent wave: the wave pulls chunks of kFetchChunk ray indices
+// from a global cursor, and every lane that finishes its ray takes the next index of the
+// chunk while its neighbours keep traversing (refill happens once at least kRefillMin lanes
+// are idle, so the reload code runs for a meaningful share of the wave).
+//   io.load(i, o, d, tmax)              ray i of the stream
+//   io.done(i, trav, valid)             called once per ray by the lane that traced it
+//   io.flush()                          called by all 64 lanes at every refill point
+//   io.finish()                         called by all 64 lanes once, after the last flush
+constexpr uint32_t kFetchChunk = 256;
+#ifndef PT_REFILL_MIN
+#define PT_REFILL_MIN 12
+#endif
+#ifndef PT_VOTE_INT
+#define PT_VOTE_INT 24   // lanes that keep the box-test loop running
+#endif
+#ifndef PT_VOTE_TRI
+#define PT_VOTE_TRI 12   // lanes that keep the triangle loop running
+#endif
+#ifndef PT_VOTE_RARE
+#define PT_VOTE_RARE 8   // lanes that make an instance enter / level change round worth running
+#endif
+constexpr int kRefillMin = PT_REFILL_MIN;
+
+template <int MODE, bool COUNT, class IO>
+PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, const LaneStack &stk, LaneEvents &ev) {
+    Traversal<MODE, COUNT> tr;
+    tr.cur = kNoRef;
+    tr.in_blas = false;
+    tr.sp = tr.base = 0;
+    bool active = false;
+    uint32_t ray_index = 0;
+    uint32_t pool_next = 0, pool_end = 0;  // wave-uniform
+    bool exhausted = false;                // wave-uniform
+    const uint32_t chunk = (n > kFetchChunk * 2u * gridDim.x) ? kFetchChunk : uint32_t(kWave);
+    const char *node_base = reinterpret_cast<const char *>(S.nodes);
+    for (;;) {
+        const uint64_t idle_mask = __ballot(!active);
+        const int idle = __popcll(idle_mask);
+        if (idle >= kRefillMin || idle == kWave) {
+            io.flush();
+            if (pool_next >= pool_end && !exhausted) {
+                uint32_t b = 0;
+                if ((threadIdx.x & 63) == 0) b = atomicAdd(cursor, chunk);
+                b = __shfl(b, 0, 64);
+                if (b >= n) {
+                    exhausted = true;
+                } else {
+                    pool_next = b;
+                    pool_end = (n - b < chunk) ? n : b + chunk;
+                }
+            }
+            if (pool_next < pool_end) {
+                const uint32_t prefix = __builtin_amdgcn_mbcnt_hi(uint32_t(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle_mask), 0u));
+                const uint32_t mine = pool_next + prefix;
+                if (!active && mine < pool_end) {
+                    PT_PHASE(ev, 5);
+                    V3 o, d;
+                    float tmax;
+                    if (io.load(mine, o, d, tmax)) {  // false: an unused slot of the stream
+                        ray_index = mine;
+                        if (tr.begin(S, o, d, tmax)) active = true;
+                        else io.done(ray_index, tr, false);
+                    }
+                }
+                const uint32_t taken = uint32_t(idle);
+                pool_next = (pool_end - pool_next < taken) ? pool_end : pool_next + taken;
+            } else if (exhausted && idle == kWave) {
+                break;
+            }
+        }
+        const bool can_refill = !(exhausted && pool_next >= pool_end);  // wave-uniform
+        PT_PHASE(ev, 7);
+
+        // ---- box-test rounds, while enough lanes take part.  The node loads are issued before
+        // the pops so that the LDS round trip hides behind them.
+        for (;;) {
+            const bool w_int = active && tr.wants_interior();
+            const bool go = __popcll(__ballot(w_int)) >= PT_VOTE_INT;
+            float4 na, nb, nc, nd;
+            if (go && w_int) {
+                const float4 *np = reinterpret_cast<const float4 *>(node_base + size_t(tr.cur << 6));
+                na = np[0];
+                nb = np[1];
+                nc = np[2];
+                nd = np[3];
+            }
+            if (active && tr.wants_pop()) {
+                PT_PHASE(ev, 3);
+                tr.pop(stk);
+            }
+            if (!go) break;
+            if (w_int) {
+                PT_PHASE(ev, 0);
+                tr.op_interior(stk, ev, na, nb, nc, nd);
+            }
+        }
+
+        // ---- the other operations, each only when enough lanes want it (or nothing else would run)
+        const bool w_int = active && tr.wants_interior();
+        const bool w_ent = active && tr.wants_enter();
+        const bool w_lvl = active && tr.wants_level();
+        const bool w_deep = active && tr.wants_deep_pop();
+        const int n_int = __popcll(__ballot(w_int));
+        int n_tri = __popcll(__ballot(active && tr.wants_triangle()));
+        const int n_ent = __popcll(__ballot(w_ent));
+        const int n_lvl = __popcll(__ballot(w_lvl || w_deep));
+        const int n_max = max(max(n_int, n_tri), max(n_ent, n_lvl));
+        if (n_max == 0) continue;  // only lanes that are still popping
+        if (n_int >= PT_VOTE_INT) continue;  // pops brought the box-test loop back above its threshold
+        if (n_int == n_max) {  // fewer than PT_VOTE_INT lanes, but still the largest group
+            if (w_int) {
+                PT_PHASE(ev, 0);
+                const float4 *np = reinterpret_cast<const float4 *>(node_base + size_t(tr.cur << 6));
+                tr.op_interior(stk, ev, np[0], np[1], np[2], np[3]);
+            }
+        }
+        if (n_tri >= PT_VOTE_TRI || n_tri == n_max) {
+            do {
+                if (active && tr.wants_triangle()) {
+                    PT_PHASE(ev, 2);
+                    if (tr.op_triangle(S)) {  // MODE_ANY only: occluded
+                        active = false;
+                        io.done(ray_index, tr, true);
+                    }
+                }
+                n_tri = __popcll(__ballot(active && tr.wants_triangle()));
+            } while (n_tri >= PT_VOTE_TRI);
+        }
+        if (n_ent > 0 && (n_ent >= PT_VOTE_RARE || n_ent == n_max)) {
+            if (w_ent) {
+                PT_PHASE(ev, 1);
+                tr.op_enter(S);
+            }
+        }
+        if (n_lvl > 0 && (n_lvl >= PT_VOTE_RARE || n_lvl == n_max || (can_refill && n_lvl + idle >= kRefillMin))) {
+            if (w_deep) tr.deep_pop(stk);
+            if (w_lvl) {
+                PT_PHASE(ev, 4);
+                if (tr.op_level(S)) {
+                    active = false;
+                    io.done(ray_index, tr, MODE == MODE_ANY ? tr.found : tr.closest_valid());
+                }
+            }
+        }
+    }
+    io.flush();
+    io.finish();
+}
+
+}  // namespace ptd
