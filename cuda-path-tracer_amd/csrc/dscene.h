@@ -49,6 +49,29 @@ struct DInstFwd {
     float4 n0, n1, n2;  // inv_transpose columns c0..c3 packed as 12 floats
     float4 m;           // total_area, bits(area_light_id), bits(triangle_sampler_index), bits(material_id)
 };
+// Vertex attributes of one triangle record (same index as DTri): what shading a hit needs.
+struct DTriShade {
+    float n[9];   // object-space normals of the three corners
+    float uv[6];  // their texture coordinates
+    float _pad;
+};
+// One emissive instance as the light sampler sees it.
+struct DLight {
+    float power;
+    int32_t gi;          // GeometryInstance index, -1: no geometry (the sample is black)
+    uint32_t tri_base;   // first entry of this light in light_alias / light_tris
+    uint32_t tri_count;
+    float total_area;
+    int32_t tex0;        // the emissive material's colour texture
+    float emittance;
+    uint32_t _pad;
+};
+// One triangle of a light in world space.
+struct DLightTri {
+    float p[9];   // corners, transform * position
+    float n[9];   // inv_transpose * normal, not normalised (kernel/light.h:35-37)
+    float uv[6];
+};
 // Unified texture descriptor for Texture<float> and Texture<glm::vec3>.
 struct DTex {
     int32_t type;
@@ -56,6 +79,10 @@ struct DTex {
     float scale[2], offset[2];
     float c0[3], c1[3];  // constant value / checkerboard colours (scalar textures use [0])
     int32_t width, height;
+    // the image behind an image texture, copied here so that a lookup goes descriptor -> texels
+    // without a third dependent load (null when image_id is out of range)
+    const void *img_data;
+    int32_t img_width, img_height;
 };
 struct DImage {
     const void *data;  // float (1 channel) or float4 (3 channels + padding)
@@ -94,6 +121,10 @@ struct DScene {
     const pt_area_light *lights;
     const DAlias *tri_samplers;
     DAlias light_sampler;
+    const DTriShade *tri_shade;
+    const DLight *dlights;
+    const uint2 *light_alias;     // {bits(probability), alias} per light triangle
+    const DLightTri *light_tris;
     uint32_t tex1_count, tex3_count, image1_count, image3_count;
     uint32_t light_count, material_count, geometry_count;
     uint32_t root_ref;

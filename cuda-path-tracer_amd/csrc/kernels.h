@@ -12,7 +12,8 @@
 
 namespace ptd {
 
-constexpr int kStageCap = 128;  // per-class staging entries per wave: < 64 carried over + <= 64 new
+constexpr int kStageFlush = 128;               // a class's staged slots are written out 128 at a time
+constexpr int kStageCap = kStageFlush + 64;    // per-class staging entries per wave: < 128 carried over + <= 64 new
 constexpr int kNumClasses = 5;  // 0 = emissive hit or miss, 1 lambertian, 2 mirror, 3 metallic-roughness, 4 dielectric
 
 // Per-bounce counters, 64 B, zeroed once per iteration for all bounces.
@@ -28,6 +29,8 @@ struct DevStats {
     uint32_t spills, drops, nan_pixels, _pad;
 };
 
+// Per-path state, one array per field, indexed by path slot.  (One 128-byte record per slot was
+// measured too: k_generate's partial-line writes made it 4x slower and k_shade gained nothing.)
 struct PathState {
     float4 *ray_o;     // origin.xyz, last_pdf
     float4 *ray_d;     // direction.xyz, bits(remaining_bounces)
@@ -37,9 +40,10 @@ struct PathState {
     uint2 *rng;        // PCG state
     float4 *hit;       // t, u, v, bits(triangle record)
     int *hit_inst;
-    float4 *sh_o;      // shadow ray origin.xyz, tmax        (indexed by shadow-queue slot)
-    float4 *sh_d;      // shadow ray direction.xyz, bits(path slot)
+    float4 *sh_o;      // shadow ray origin.xyz, tmax        (indexed by path slot, like everything above)
+    float4 *sh_d;      // shadow ray direction.xyz
     float4 *sh_c;      // contribution added when unoccluded
+    uint32_t *sh_q;    // path slots with a pending shadow ray
     uint32_t *ext_q[2];
     uint32_t *class_q[kNumClasses];
     uint32_t capacity;  // path slots = samples_in_flight * slots_per_sample
@@ -319,13 +323,14 @@ struct ExtendIO {
             const uint32_t prefix = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
             if (mine) stage[k * kStageCap + staged[k] + prefix] = pend_slot;
             staged[k] += uint32_t(__popcll(mask));
-            if (staged[k] >= kWave) {
+            if (staged[k] >= kStageFlush) {
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&bc->class_count[k], uint32_t(kWave));
+                if (lane == 0) base = atomicAdd(&bc->class_count[k], uint32_t(kStageFlush));
                 base = __shfl(base, 0, 64);
-                P.class_q[k][base + lane] = stage[k * kStageCap + lane];
-                const uint32_t rest = staged[k] - kWave;
-                const uint32_t moved = (lane < rest) ? stage[k * kStageCap + kWave + lane] : 0u;
+#pragma unroll
+                for (int r = 0; r < kStageFlush / kWave; ++r) P.class_q[k][base + r * kWave + lane] = stage[k * kStageCap + r * kWave + lane];
+                const uint32_t rest = staged[k] - kStageFlush;  // < 64
+                const uint32_t moved = (lane < rest) ? stage[k * kStageCap + kStageFlush + lane] : 0u;
                 if (lane < rest) stage[k * kStageCap + lane] = moved;
                 staged[k] = rest;
             }
@@ -364,7 +369,35 @@ __global__ __launch_bounds__(64) void k_extend(DScene S, PathState P, BounceCoun
 // (:337-389) for class 0, as one persistent launch whose waves each work on a single class.
 // Next-event estimation is split off: the light sample and its full contribution are computed
 // here, the visibility test runs in k_shadow, which adds the contribution when unoccluded.
+//
+// Same-address atomics serialise at ~12 ns each, so a wave takes kShadeGroup chunks of 64 paths
+// per work fetch when the queues are long, stages the slots it emits (next bounce's extension
+// rays, shadow rays) in LDS and appends them with one atomic per queue and group.
+constexpr uint32_t kShadeGroup = 8;
+
+// Diagnostic build only (-DPT_PHASE_PROF -DPT_SHADE_STAMPS): wave clock spent between the marked
+// points of k_shade, every stamp first waiting for all outstanding memory operations.
+#ifdef PT_SHADE_STAMPS
+#define PT_STAMP(k)                                                                                          \
+    do {                                                                                                     \
+        unsigned long long t_;                                                                               \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+        stamp_acc[k] += t_ - stamp_last;                                                                     \
+        stamp_last = t_;                                                                                     \
+    } while (0)
+#else
+#define PT_STAMP(k) do { } while (0)
+#endif
+constexpr int kShadeWavesPerCu = 16;
+
+// The kernel is bound by the latency of its dependent gathers (path state, vertex data, texels:
+// ~2500 cycles per L2 miss measured), not by VALU work (forcing more waves per SIMD through
+// register spilling made it slower).  So the loads are organised in levels: everything whose
+// address is known is requested before anything is waited for, and the hit chain (triangle ->
+// indices -> vertex attributes -> textures) advances level by level together with the light
+// chain (light pick -> instance -> triangle pick -> indices -> vertices -> texture).
 __global__ __launch_bounds__(64) void k_shade(DScene S, PathState P, BounceCounters *cnt, int bounce) {
+    __shared__ uint32_t stage_ext[kShadeGroup * kWave], stage_sh[kShadeGroup * kWave];
     const uint32_t lane = threadIdx.x;
     BounceCounters *bc = cnt + bounce;
     uint32_t chunk_start[kNumClasses + 1];
@@ -372,9 +405,18 @@ __global__ __launch_bounds__(64) void k_shade(DScene S, PathState P, BounceCount
 #pragma unroll
     for (int k = 0; k < kNumClasses; ++k) chunk_start[k + 1] = chunk_start[k] + ((bc->class_count[k] + kWave - 1) >> 6);
     const uint32_t total_chunks = chunk_start[kNumClasses];
+    const uint32_t group = (total_chunks >= 4u * kShadeGroup * gridDim.x) ? kShadeGroup : (total_chunks >= 8u * gridDim.x ? 2u : 1u);
+#ifdef PT_SHADE_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
     for (;;) {
-        const uint32_t chunk = wave_fetch(&bc->cur_shade, 1);
-        if (chunk >= total_chunks) break;
+      PT_STAMP(7);
+      const uint32_t first_chunk = wave_fetch(&bc->cur_shade, group);
+      if (first_chunk >= total_chunks) break;
+      const uint32_t end_chunk = (total_chunks - first_chunk < group) ? total_chunks : first_chunk + group;
+      uint32_t n_ext = 0, n_sh = 0;  // wave-uniform fill levels of the staging areas
+      for (uint32_t chunk = first_chunk; chunk < end_chunk; ++chunk) {
         int cls = 0;
 #pragma unroll
         for (int k = 1; k < kNumClasses; ++k)
@@ -385,6 +427,7 @@ __global__ __launch_bounds__(64) void k_shade(DScene S, PathState P, BounceCount
         uint32_t slot = 0;
         float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_c = sh_o;
         if (active) {
+            PT_STAMP(0);
             slot = P.class_q[cls][qi];
             const float4 ro4 = P.ray_o[slot], rd4 = P.ray_d[slot];
             const V3 ro = mk3(ro4.x, ro4.y, ro4.z), rd = mk3(rd4.x, rd4.y, rd4.z);
@@ -422,16 +465,141 @@ __global__ __launch_bounds__(64) void k_shade(DScene S, PathState P, BounceCount
                 }
                 P.accum[slot] = make_float4(accum.x, accum.y, accum.z, 0.0f);
             } else {
+                // ---- level A: the rest of the path state (requested together with the loads above)
                 const float4 h4 = P.hit[slot];
-                const Isect is = resolve_hit(S, ro, rd, h4.y, h4.z, as_u(h4.w), inst);
-                const DMaterial m = S.materials[is.material_id];
-                const uint32_t mtype = m.type & 0xFFu;
                 const uint2 r2 = P.rng[slot];
                 uint64_t rng = uint64_t(r2.x) | (uint64_t(r2.y) << 32);
+                const float hu = h4.y, hv = h4.z;
+                const uint32_t rec = as_u(h4.w);
+                const bool specular = (cls == 2 || cls == 4);  // the class is the material type (k_extend)
+                const bool nee = !specular && S.light_count > 0;
+                // kernel/light.h:15-59 draws: light pick, triangle pick, point (2).  An invalid light
+                // returns after the first draw, so the later three are taken from a copy.
+                AliasPick pick{0, 0.0f};
+                uint64_t rng_l = rng;
+                if (nee) pick = alias_begin(S.light_sampler.size, sample1d(rng_l));
+                const uint64_t rng_after_pick = rng_l;
+                float x_tri = 0.0f, lsx = 0.0f, lsy = 0.0f;
+                if (nee) {
+                    x_tri = sample1d(rng_l);
+                    lsx = sample1d(rng_l);
+                    lsy = sample1d(rng_l);
+                }
+                // Loads that miss the caches (path state above, triangle records, texels, light
+                // triangles) are requested in batches; the small tables in between (instances,
+                // materials, texture and light descriptors) are cache hits and are read where needed,
+                // which keeps the register count, and with it the waves per SIMD, in check.
+                PT_STAMP(1);
+                // ---- level B: triangle corners and vertex attributes
+                const float4 *tp = reinterpret_cast<const float4 *>(S.tris + rec);
+                const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+                const float4 *sp = reinterpret_cast<const float4 *>(S.tri_shade + rec);
+                const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+                // light pick -> light descriptor -> triangle pick (small tables, then one pair per triangle)
+                DLight light;
+                light.power = 0.0f;
+                light.gi = -1;
+                light.tri_base = 0;
+                light.tri_count = 1;
+                light.total_area = 1.0f;
+                light.tex0 = -1;
+                light.emittance = 0.0f;
+                if (nee) {
+                    const uint32_t light_id = alias_end(pick, S.light_sampler.prob[pick.i], S.light_sampler.alias[pick.i]);
+                    light = S.dlights[light_id];
+                }
+                const bool lvalid = nee && light.gi != -1;
+                if (nee) rng = lvalid ? rng_l : rng_after_pick;
+                const AliasPick tpick = alias_begin(light.tri_count, x_tri);
+                uint2 la = make_uint2(0u, 0u);
+                if (lvalid) la = S.light_alias[light.tri_base + tpick.i];
+                const float4 idv = reinterpret_cast<const float4 *>(S.insts + inst)[3];
+                const int mid = int(as_u(idv.y));
+                const DMaterial m = S.materials[mid];
+                const uint32_t mtype = m.type & 0xFFu;
+                Isect is;  // resolve_hit(), shade.h
+                {
+                    const float4 *fp = reinterpret_cast<const float4 *>(S.fwd + inst);
+                    const M34 T = load_m34(fp[0], fp[1], fp[2]);
+                    const M34 N = load_m34(fp[3], fp[4], fp[5]);
+                    const V3 p0 = mk3(ta.x, ta.y, ta.z), p1 = mk3(ta.w, tb.x, tb.y), p2 = mk3(tb.z, tb.w, tc.x);
+                    const V3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
+                    const V2 uv0 = V2{s2.y, s2.z}, uv1 = V2{s2.w, s3.x}, uv2 = V2{s3.y, s3.z};
+                    const float w = 1.0f - hu - hv;
+                    const V3 best_normal = normalize(w * n0 + hu * n1 + hv * n2);
+                    const V2 best_uv = w * uv0 + hu * uv1 + hv * uv2;
+                    const V3 best_pos = w * p0 + hu * p1 + hv * p2;
+                    is.pos = xform(T, best_pos, 1.0f);
+                    is.uv = best_uv;
+                    is.time = dot(is.pos - ro, rd);
+                    is.normal = normalize(xform(N, best_normal, 0.0f));
+                    is.material_id = mid;
+                    is.geometry_id = inst;
+                }
+                PT_STAMP(2);
+                // ---- level C: texels of the material's textures; the picked light triangle
+                const bool is_mr = (mtype == PT_MAT_METALLIC_ROUGHNESS);
+                const TexReq R0 = tex_request(S.tex3, S.tex3_count, m.tex0, is.uv);
+                const TexReq R1 = tex_request(S.tex1, is_mr ? S.tex1_count : 0u, int(m.w1), is.uv);
+                const TexReq R2 = tex_request(S.tex1, is_mr ? S.tex1_count : 0u, m.w2, is.uv);
+                float4 a00 = make_float4(0, 0, 0, 0), a10 = a00, a01 = a00, a11 = a00;
+                if (R0.p.mode == 3) {
+                    const float4 *d = static_cast<const float4 *>(R0.data);
+                    a00 = d[R0.p.o00]; a10 = d[R0.p.o10]; a01 = d[R0.p.o01]; a11 = d[R0.p.o11];
+                }
+                float b00 = 0, b10 = 0, b01 = 0, b11 = 0, c00 = 0, c10 = 0, c01 = 0, c11 = 0;
+                if (R1.p.mode == 3) {
+                    const float *d = static_cast<const float *>(R1.data);
+                    b00 = d[R1.p.o00]; b10 = d[R1.p.o10]; b01 = d[R1.p.o01]; b11 = d[R1.p.o11];
+                }
+                if (R2.p.mode == 3) {
+                    const float *d = static_cast<const float *>(R2.data);
+                    c00 = d[R2.p.o00]; c10 = d[R2.p.o10]; c01 = d[R2.p.o01]; c11 = d[R2.p.o11];
+                }
+                const uint32_t ltri = alias_end(tpick, as_f(la.x), la.y);
+                float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0, g3 = g0, g4 = g0, g5 = g0;
+                if (lvalid) {
+                    const float4 *lt = reinterpret_cast<const float4 *>(S.light_tris + (light.tri_base + ltri));
+                    g0 = lt[0]; g1 = lt[1]; g2 = lt[2]; g3 = lt[3]; g4 = lt[4]; g5 = lt[5];
+                }
+                // the material's textures are looked up once per hit; the reference's sample / eval /
+                // pdf routines each repeat the same lookups (metallic_roughness.h:8-177)
+                PT_STAMP(3);
+                const V3 albedo = tex3_finish(R0, a00, a10, a01, a11);
+                MRParams mr;
+                mr.base_color = albedo;
+                mr.metallic = tex1_finish(R1, b00, b10, b01, b11);
+                {
+                    float alpha = tex1_finish(R2, c00, c10, c01, c11);
+                    alpha = gmin(gmax(alpha, 0.02f), 1.0f);
+                    mr.alpha = alpha * alpha;
+                }
                 const V3 w_out = -normalize(rd);
-                const bool specular = (mtype == PT_MAT_MIRROR || mtype == PT_MAT_DIELECTRIC);
-                if (!specular && S.light_count > 0) {
-                    const LightSample ls = sample_scene_light(S, rng);
+                LightSample ls;
+                ls.position = ls.normal = ls.radiance = splat(0.0f);
+                ls.pdf = 0.0f;
+                if (lvalid) {
+                    const V3 p0 = mk3(g0.x, g0.y, g0.z), p1 = mk3(g0.w, g1.x, g1.y), p2 = mk3(g1.z, g1.w, g2.x);
+                    const V3 n0 = mk3(g2.y, g2.z, g2.w), n1 = mk3(g3.x, g3.y, g3.z), n2 = mk3(g3.w, g4.x, g4.y);
+                    const V2 t0 = V2{g4.z, g4.w}, t1 = V2{g5.x, g5.y}, t2 = V2{g5.z, g5.w};
+                    const float sqr = sqrtf(lsx);  // Math::SampleTriangle, math/sampling.h:61-68
+                    const float u = 1.0f - sqr;
+                    const float v = lsy * sqr;
+                    const float w = 1.0f - u - v;
+                    ls.position = u * p0 + v * p1 + w * p2;
+                    ls.normal = u * n0 + v * n1 + w * n2;  // un-normalised on purpose (kernel/light.h:47,54)
+                    const V2 texcoord = u * t0 + v * t1 + w * t2;
+                    // ---- level D: the light's texels
+                    const TexReq LR = tex_request(S.tex3, S.tex3_count, light.tex0, texcoord);
+                    float4 e00 = make_float4(0, 0, 0, 0), e10 = e00, e01 = e00, e11 = e00;
+                    if (LR.p.mode == 3) {
+                        const float4 *d = static_cast<const float4 *>(LR.data);
+                        e00 = d[LR.p.o00]; e10 = d[LR.p.o10]; e01 = d[LR.p.o01]; e11 = d[LR.p.o11];
+                    }
+                    ls.radiance = tex3_finish(LR, e00, e10, e01, e11) * light.emittance;
+                    ls.pdf = (light.power / S.total_light_power) * (1.0f / light.total_area);
+                }
+                if (nee) {
                     const V3 w_in = normalize(ls.position - is.pos);
                     const float dist = length(is.pos - ls.position);
                     const float cos_surf = dot(is.normal, w_in);
@@ -440,11 +608,11 @@ __global__ __launch_bounds__(64) void k_shade(DScene S, PathState P, BounceCount
                         V3 bsdf;
                         float bsdf_pdf;
                         if (mtype == PT_MAT_LAMBERTIAN) {
-                            bsdf = sample_tex3(S, m.tex0, is.uv) * kInvPi;
+                            bsdf = albedo * kInvPi;
                             bsdf_pdf = fmaxf(0.0f, dot(is.normal, w_in)) * kInvPi;
                         } else {
-                            bsdf = eval_metallic_roughness(S, m, is, w_in, w_out);
-                            bsdf_pdf = metallic_roughness_pdf(S, m, is, w_in, w_out);
+                            bsdf = eval_metallic_roughness(mr, is, w_in, w_out);
+                            bsdf_pdf = metallic_roughness_pdf(mr, is, w_in, w_out);
                         }
                         const float light_pdf = ls.pdf * dist * dist / cos_light;
                         const float light_weight = power_heuristic(light_pdf, bsdf_pdf);
@@ -452,16 +620,17 @@ __global__ __launch_bounds__(64) void k_shade(DScene S, PathState P, BounceCount
                         const V3 so = is.pos + kEps * w_in;
                         const float tmax = float(double(dist) - 1e-4);  // path_trace.cu:228
                         sh_o = make_float4(so.x, so.y, so.z, tmax);
-                        sh_d = make_float4(w_in.x, w_in.y, w_in.z, as_f(slot));
+                        sh_d = make_float4(w_in.x, w_in.y, w_in.z, 0.0f);
                         sh_c = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
                         want_shadow = true;
                     }
                 }
+                PT_STAMP(4);
                 BsdfSample sample;
-                if (mtype == PT_MAT_LAMBERTIAN) sample = sample_lambertian(S, m, is, rng);
-                else if (mtype == PT_MAT_MIRROR) sample = sample_mirror(S, m, is, w_out);
-                else if (mtype == PT_MAT_DIELECTRIC) sample = sample_dielectric(S, m, is, w_out, rng);
-                else sample = sample_metallic_roughness(S, m, is, w_out, rng);
+                if (mtype == PT_MAT_LAMBERTIAN) sample = sample_lambertian(albedo, is, rng);
+                else if (mtype == PT_MAT_MIRROR) sample = sample_mirror(albedo, is, w_out);
+                else if (mtype == PT_MAT_DIELECTRIC) sample = sample_dielectric(albedo, m, is, w_out, rng);
+                else sample = sample_metallic_roughness(mr, is, w_out, rng);
                 const float cos_surf = fabsf(dot(is.normal, sample.w_in));
                 bool alive = !(sample.pdf < kEps || cos_surf < kEps || sample.type == S_Invalid);
                 float new_last_pdf = last_pdf;
@@ -493,15 +662,37 @@ __global__ __launch_bounds__(64) void k_shade(DScene S, PathState P, BounceCount
                 P.rng[slot] = make_uint2(uint32_t(rng), uint32_t(rng >> 32));
             }
         }
-        const uint32_t sq = wave_append(&bc->shadow_count, want_shadow);
         if (want_shadow) {
-            P.sh_o[sq] = sh_o;
-            P.sh_d[sq] = sh_d;
-            P.sh_c[sq] = sh_c;
+            P.sh_o[slot] = sh_o;
+            P.sh_d[slot] = sh_d;
+            P.sh_c[slot] = sh_c;
         }
-        const uint32_t eq = wave_append(&bc[1].ext_count, want_extend);
-        if (want_extend) P.ext_q[(bounce + 1) & 1][eq] = slot;
+        PT_STAMP(5);
+        const uint64_t m_sh = __builtin_amdgcn_ballot_w64(want_shadow);
+        if (want_shadow) stage_sh[n_sh + __builtin_amdgcn_mbcnt_hi(uint32_t(m_sh >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m_sh), 0u))] = slot;
+        n_sh += uint32_t(__builtin_popcountll(m_sh));
+        const uint64_t m_ext = __builtin_amdgcn_ballot_w64(want_extend);
+        if (want_extend) stage_ext[n_ext + __builtin_amdgcn_mbcnt_hi(uint32_t(m_ext >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m_ext), 0u))] = slot;
+        n_ext += uint32_t(__builtin_popcountll(m_ext));
+      }
+      // ---- append the group's output to the global queues: one atomic each
+      __syncthreads();  // one wave per block: orders the staging writes before the reads below
+      if (n_sh > 0) {
+          const uint32_t base = wave_fetch(&bc->shadow_count, n_sh);
+          for (uint32_t i = lane; i < n_sh; i += kWave) P.sh_q[base + i] = stage_sh[i];
+      }
+      if (n_ext > 0) {
+          const uint32_t base = wave_fetch(&bc[1].ext_count, n_ext);
+          uint32_t *q = P.ext_q[(bounce + 1) & 1];
+          for (uint32_t i = lane; i < n_ext; i += kWave) q[base + i] = stage_ext[i];
+      }
+      __syncthreads();  // the staging areas are reused by the next group
+      PT_STAMP(6);
     }
+#ifdef PT_SHADE_STAMPS
+    if (lane == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_phase_prof[k], stamp_acc[k]);
+#endif
 }
 
 // The visibility half of next-event estimation (path_trace.cu:221-243): IntersectScene<ANY> with
@@ -511,12 +702,12 @@ struct ShadowIO {
     uint32_t slot = 0;
     float4 contrib;
     PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax) {
-        const float4 so = P.sh_o[i], sd = P.sh_d[i];
-        contrib = P.sh_c[i];
+        slot = P.sh_q[i];
+        const float4 so = P.sh_o[slot], sd = P.sh_d[slot];
+        contrib = P.sh_c[slot];
         o = mk3(so.x, so.y, so.z);
         d = mk3(sd.x, sd.y, sd.z);
         tmax = so.w;
-        slot = as_u(sd.w);
         return true;
     }
     PTD void done(uint32_t, const Traversal<MODE_ANY, false> &, bool occluded) const {

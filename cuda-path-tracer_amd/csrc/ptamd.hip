@@ -499,6 +499,10 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
     // ---- triangle records in leaf order
     std::vector<DTri> tris(d->tri_index_count);
     std::memset(tris.data(), 0, tris.size() * sizeof(DTri));
+    // ... and, under the same record index, the vertex attributes a hit needs for shading: one
+    // 64-byte record instead of three index reads and six scattered attribute reads
+    std::vector<DTriShade> tri_shade(d->tri_index_count);
+    std::memset(tri_shade.data(), 0, tri_shade.size() * sizeof(DTriShade));
     for (uint32_t b = 0; b < d->blas_count; ++b) {
         const pt_blas &blas = d->blases[b];
         if (blas.node_count == 0 || blas_owner[b] < 0) continue;
@@ -512,6 +516,12 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
             r.a = make_float4(p[0][0], p[0][1], p[0][2], p[1][0]);
             r.b = make_float4(p[1][1], p[1][2], p[2][0], p[2][1]);
             r.c = make_float4(p[2][2], __builtin_bit_cast(float, tri), 0.0f, 0.0f);
+            DTriShade &sh = tri_shade[blas.first_index + j];
+            for (int k = 0; k < 3; ++k) {
+                const size_t v = d->indices[g.first_index + tri * 3 + k];
+                for (int c = 0; c < 3; ++c) sh.n[3 * k + c] = d->normals[3 * v + c];
+                for (int c = 0; c < 2; ++c) sh.uv[2 * k + c] = d->uvs[2 * v + c];
+            }
         }
     }
 
@@ -667,6 +677,18 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
         if (st != PT_OK) return st;
         img3[i] = DImage{dev, im.width, im.height};
     }
+    for (DTex &t : tex1)
+        if (t.type == PT_TEX_IMAGE && t.image_id >= 0 && uint32_t(t.image_id) < d->image1_count) {
+            t.img_data = img1[t.image_id].data;
+            t.img_width = img1[t.image_id].width;
+            t.img_height = img1[t.image_id].height;
+        }
+    for (DTex &t : tex3)
+        if (t.type == PT_TEX_IMAGE && t.image_id >= 0 && uint32_t(t.image_id) < d->image3_count) {
+            t.img_data = img3[t.image_id].data;
+            t.img_width = img3[t.image_id].width;
+            t.img_height = img3[t.image_id].height;
+        }
 
     // ---- alias tables
     std::vector<DAlias> tri_samplers(d->triangle_sampler_count);
@@ -687,8 +709,64 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
         S.light_sampler = DAlias{p, a, d->light_sampler->size, 0};
     }
 
+    // ---- light sampling records: what kernel/light.h:15-59 gathers per sample through
+    // light -> instance -> alias table -> indices -> 9 vertex attributes is laid out per light as
+    // one descriptor, one {probability, alias} pair per triangle and one 96-byte record per
+    // triangle holding the world-space corners, transformed normals and uvs.  The transforms
+    // are evaluated here with the device's operation order, so the values are the same bits.
+    std::vector<DLight> dlights(d->light_count);
+    std::vector<uint2> light_alias;
+    std::vector<DLightTri> light_tris;
+    for (uint32_t li = 0; li < d->light_count; ++li) {
+        DLight &L = dlights[li];
+        std::memset(&L, 0, sizeof(L));
+        L.power = d->lights[li].power;
+        L.gi = d->lights[li].geometry_instance_index;
+        L.tex0 = -1;
+        if (L.gi < 0) {
+            L.gi = -1;
+            continue;
+        }
+        const pt_geometry_instance &g = d->geometries[L.gi];
+        if (g.triangle_sampler_index < 0 || uint32_t(g.triangle_sampler_index) >= d->triangle_sampler_count)
+            return Fail(ctx, PT_ERR_INVALID, "light %u: instance %d has no triangle sampler", li, L.gi);
+        const pt_alias_table &t = d->triangle_samplers[g.triangle_sampler_index];
+        if (t.size != g.index_count / 3) return Fail(ctx, PT_ERR_INVALID, "light %u: sampler size %u differs from the mesh's %u triangles", li, t.size, g.index_count / 3);
+        L.tri_base = uint32_t(light_tris.size());
+        L.tri_count = t.size;
+        L.total_area = g.total_area;
+        L.tex0 = d->materials[g.material_id].tex0;
+        std::memcpy(&L.emittance, &d->materials[g.material_id].w1, 4);
+        const DInstFwd &f = fwd[L.gi];
+        const float Tm[12] = {f.t0.x, f.t0.y, f.t0.z, f.t0.w, f.t1.x, f.t1.y, f.t1.z, f.t1.w, f.t2.x, f.t2.y, f.t2.z, f.t2.w};
+        const float Nm[12] = {f.n0.x, f.n0.y, f.n0.z, f.n0.w, f.n1.x, f.n1.y, f.n1.z, f.n1.w, f.n2.x, f.n2.y, f.n2.z, f.n2.w};
+        auto xf = [](const float *m, const float *v, float w, float *out) {  // xform(), dmath.h
+            for (int c = 0; c < 3; ++c) {
+                const float a = m[c] * v[0] + m[3 + c] * v[1];
+                const float b = m[6 + c] * v[2] + m[9 + c] * w;
+                out[c] = a + b;
+            }
+        };
+        for (uint32_t tri = 0; tri < t.size; ++tri) {
+            light_alias.push_back(make_uint2(__builtin_bit_cast(uint32_t, t.probability_table[tri]), t.alias_table[tri]));
+            DLightTri r;
+            for (int k = 0; k < 3; ++k) {
+                const size_t v = d->indices[g.first_index + tri * 3 + k];
+                xf(Tm, d->positions + 3 * v, 1.0f, r.p + 3 * k);
+                xf(Nm, d->normals + 3 * v, 0.0f, r.n + 3 * k);
+                r.uv[2 * k] = d->uvs[2 * v];
+                r.uv[2 * k + 1] = d->uvs[2 * v + 1];
+            }
+            light_tris.push_back(r);
+        }
+    }
+
 #define UP(field, vec)                                                                             \
     if ((st = Upload(ctx, ctx->scene_allocs, (vec).data(), (vec).size(), &S.field)) != PT_OK) return st
+    UP(tri_shade, tri_shade);
+    UP(dlights, dlights);
+    UP(light_alias, light_alias);
+    UP(light_tris, light_tris);
     if (nodes.empty()) nodes.emplace_back();  // lanes without work read record 0 of this array
     UP(nodes, nodes);
     UP(tris, tris);
@@ -741,7 +819,7 @@ static int EnsurePaths(pt_ctx *ctx, uint32_t samples) {
     std::memset(&P, 0, sizeof(P));
     int st = PT_OK;
 #define AL(field) if ((st = Alloc(ctx, ctx->state_allocs, cap, &P.field)) != PT_OK) return st
-    AL(ray_o); AL(ray_d); AL(thr); AL(accum); AL(last_pos); AL(rng); AL(hit); AL(hit_inst); AL(sh_o); AL(sh_d); AL(sh_c);
+    AL(ray_o); AL(ray_d); AL(thr); AL(accum); AL(last_pos); AL(rng); AL(hit); AL(hit_inst); AL(sh_o); AL(sh_d); AL(sh_c); AL(sh_q);
     AL(ext_q[0]); AL(ext_q[1]);
     for (int k = 0; k < kNumClasses; ++k) AL(class_q[k]);
 #undef AL
@@ -874,6 +952,14 @@ int pt_render_batch(pt_ctx *ctx, int width, int height, int iteration, int sampl
     }
     HIP_TRY(ctx, hipGetLastError());
     ctx->last_render_samples = samples;
+    if (getenv("PTAMD_DEBUG_QUEUES")) {  // tuning aid: per-bounce queue sizes of this pass on stderr
+        std::vector<BounceCounters> h(size_t(ctx->last_render_bounces) + 1);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpy(h.data(), ctx->counters, h.size() * sizeof(BounceCounters), hipMemcpyDeviceToHost));
+        for (size_t b = 0; b < h.size(); ++b)
+            fprintf(stderr, "[ptamd] bounce %zu: extend %u, classes %u %u %u %u %u, shadow %u\n", b, h[b].ext_count, h[b].class_count[0],
+                    h[b].class_count[1], h[b].class_count[2], h[b].class_count[3], h[b].class_count[4], h[b].shadow_count);
+    }
     return PT_OK;
 }
 

@@ -75,8 +75,8 @@ PTD V3 sample_tex3(const DScene &S, int id, V2 uv) {
         return ((i + j) & 1) ? mk3(t.c1[0], t.c1[1], t.c1[2]) : mk3(t.c0[0], t.c0[1], t.c0[2]);
     }
     if (t.type == PT_TEX_IMAGE) {
-        if (t.image_id < 0 || uint32_t(t.image_id) >= S.image3_count) return splat(0.0f);
-        return sample_image3(S.images3[t.image_id], s, tt);
+        if (!t.img_data) return splat(0.0f);
+        return sample_image3(DImage{t.img_data, t.img_width, t.img_height}, s, tt);
     }
     return splat(0.0f);
 }
@@ -91,8 +91,8 @@ PTD float sample_tex1(const DScene &S, int id, V2 uv) {
         return ((i + j) & 1) ? t.c1[0] : t.c0[0];
     }
     if (t.type == PT_TEX_IMAGE) {
-        if (t.image_id < 0 || uint32_t(t.image_id) >= S.image1_count) return 0.0f;
-        return sample_image1(S.images1[t.image_id], s, tt);
+        if (!t.img_data) return 0.0f;
+        return sample_image1(DImage{t.img_data, t.img_width, t.img_height}, s, tt);
     }
     return 0.0f;
 }
@@ -235,10 +235,9 @@ PTD MRParams mr_fetch(const DScene &S, const DMaterial &m, const Isect &is) {
     return p;
 }
 
-PTD BsdfSample sample_lambertian(const DScene &S, const DMaterial &m, const Isect &is, uint64_t &rng) {  // lambertian.h:5-23
+PTD BsdfSample sample_lambertian(V3 albedo, const Isect &is, uint64_t &rng) {  // lambertian.h:5-23
     const float sx = sample1d(rng), sy = sample1d(rng);
     const V3 w_in = sample_cosine_hemisphere(is.normal, sx, sy);
-    const V3 albedo = sample_tex3(S, m.tex0, is.uv);
     BsdfSample r;
     r.bsdf = albedo * kInvPi;
     r.pdf = fmaxf(0.0f, dot(is.normal, w_in)) * kInvPi;
@@ -246,17 +245,17 @@ PTD BsdfSample sample_lambertian(const DScene &S, const DMaterial &m, const Isec
     r.w_in = w_in;
     return r;
 }
-PTD BsdfSample sample_mirror(const DScene &S, const DMaterial &m, const Isect &is, V3 w_out) {  // perfect_mirror.h:5-23
+PTD BsdfSample sample_mirror(V3 albedo, const Isect &is, V3 w_out) {  // perfect_mirror.h:5-23
     const V3 w_in = reflect(w_out, is.normal);
     const float cos_in = fabsf(dot(is.normal, w_in));
     BsdfSample r;
     r.pdf = 1.0f;
     r.w_in = w_in;
     r.type = S_Specular | S_Reflection;
-    r.bsdf = sample_tex3(S, m.tex0, is.uv) / cos_in;
+    r.bsdf = albedo / cos_in;
     return r;
 }
-PTD BsdfSample sample_dielectric(const DScene &S, const DMaterial &m, const Isect &is, V3 w_out, uint64_t &rng) {  // perfect_dielectric.h:5-66
+PTD BsdfSample sample_dielectric(V3 color, const DMaterial &m, const Isect &is, V3 w_out, uint64_t &rng) {  // perfect_dielectric.h:5-66
     BsdfSample result;
     result.type = S_Invalid;
     result.pdf = 0.0f;
@@ -273,7 +272,6 @@ PTD BsdfSample sample_dielectric(const DScene &S, const DMaterial &m, const Isec
     }
     const float reflectance = fresnel(cos_out, eta);
     const float transmittance = 1.0f - reflectance;
-    const V3 color = sample_tex3(S, m.tex0, is.uv);
     if (sample1d(rng) < reflectance) {
         const V3 w_in = reflect(w_out, normal);
         const float cos_in = dot(normal, normalize(w_in));
@@ -295,7 +293,7 @@ PTD BsdfSample sample_dielectric(const DScene &S, const DMaterial &m, const Isec
     result.pdf = transmittance;
     return result;
 }
-PTD BsdfSample sample_metallic_roughness(const DScene &S, const DMaterial &m, const Isect &is, V3 w_out, uint64_t &rng) {  // metallic_roughness.h:8-90
+PTD BsdfSample sample_metallic_roughness(const MRParams &p, const Isect &is, V3 w_out, uint64_t &rng) {  // metallic_roughness.h:8-90
     BsdfSample result;
     result.type = S_Invalid;
     result.pdf = 0.0f;
@@ -307,7 +305,6 @@ PTD BsdfSample sample_metallic_roughness(const DScene &S, const DMaterial &m, co
         normal = -normal;
         cos_out = -cos_out;
     }
-    const MRParams p = mr_fetch(S, m, is);
     const V3 F0 = mix3(splat(0.04f), p.base_color, p.metallic);
     float w_diff = luminance(p.base_color) * (1.0f - p.metallic);
     float w_spec = luminance(F0);
@@ -344,12 +341,11 @@ PTD BsdfSample sample_metallic_roughness(const DScene &S, const DMaterial &m, co
     result.pdf = w_diff * cos_in * kInvPi;
     return result;
 }
-PTD V3 eval_metallic_roughness(const DScene &S, const DMaterial &m, const Isect &is, V3 w_in, V3 w_out) {  // metallic_roughness.h:92-127
+PTD V3 eval_metallic_roughness(const MRParams &p, const Isect &is, V3 w_in, V3 w_out) {  // metallic_roughness.h:92-127
     const V3 normal = is.normal;
     const float cos_out = dot(normal, w_out);
     const float cos_in = dot(normal, w_in);
     if (cos_out <= 0.0f || cos_in <= 0.0f) return splat(0.0f);
-    const MRParams p = mr_fetch(S, m, is);
     const V3 half_vec = normalize(w_in + w_out);
     const V3 F0 = mix3(splat(0.04f), p.base_color, p.metallic);
     const float D = trowbridge_reitz(normal, half_vec, p.alpha);
@@ -360,12 +356,11 @@ PTD V3 eval_metallic_roughness(const DScene &S, const DMaterial &m, const Isect 
     const V3 diffuse = p.base_color * (1.0f - p.metallic) * (1.0f - refl_out) * (1.0f - refl_in) * kInvPi;
     return diffuse + specular;
 }
-PTD float metallic_roughness_pdf(const DScene &S, const DMaterial &m, const Isect &is, V3 w_in, V3 w_out) {  // metallic_roughness.h:129-177
+PTD float metallic_roughness_pdf(const MRParams &p, const Isect &is, V3 w_in, V3 w_out) {  // metallic_roughness.h:129-177
     const V3 normal = is.normal;
     const float cos_out = dot(normal, w_out);
     const float cos_in = dot(normal, w_in);
     if (cos_out <= 0.0f || cos_in <= 0.0f) return 0.0f;
-    const MRParams p = mr_fetch(S, m, is);
     const V3 F0 = mix3(splat(0.04f), p.base_color, p.metallic);
     float w_diff = luminance(p.base_color) * (1.0f - p.metallic);
     float w_spec = luminance(F0);
@@ -430,6 +425,108 @@ PTD LightSample sample_scene_light(const DScene &S, uint64_t &rng) {  // kernel/
     ls.pdf = p_pick * (1.0f / total_area);
     return ls;
 }
+
+// ------------------------------------------------ lookups split into load levels
+// The same arithmetic as sample_tex3 / sample_tex1 / discrete_sample above, cut at every point
+// where a load depends on an earlier one, so that a caller can request all loads of one level
+// (for several textures and for the light chain) before it waits for any of them.
+struct TexPlan {
+    int mode;  // 0: value 0, 1: c0, 2: c1, 3: image (four taps at the offsets below)
+    uint32_t o00, o10, o01, o11;
+    float fx, fy;
+};
+PTD TexPlan tex_plan(const DTex &t, bool valid, V2 uv) {
+    TexPlan p;
+    p.mode = 0;
+    p.o00 = p.o10 = p.o01 = p.o11 = 0;
+    p.fx = p.fy = 0.0f;
+    if (!valid) return p;
+    if (t.type == PT_TEX_CONSTANT) {
+        p.mode = 1;
+        return p;
+    }
+    const float s = uv.x * t.scale[0] + t.offset[0];
+    const float tt = uv.y * t.scale[1] + t.offset[1];
+    if (t.type == PT_TEX_CHECKERBOARD) {
+        const int i = int(floorf(s)), j = int(floorf(tt));
+        p.mode = ((i + j) & 1) ? 2 : 1;
+        return p;
+    }
+    if (t.type != PT_TEX_IMAGE || !t.img_data) return p;
+    if (!isfinite(s) || !isfinite(tt) || t.img_width <= 0 || t.img_height <= 0) return p;
+    int i0, i1, j0, j1;
+    bilinear_setup(DImage{t.img_data, t.img_width, t.img_height}, s, tt, i0, i1, j0, j1, p.fx, p.fy);
+    p.o00 = uint32_t(j0) * uint32_t(t.img_width) + uint32_t(i0);
+    p.o10 = uint32_t(j0) * uint32_t(t.img_width) + uint32_t(i1);
+    p.o01 = uint32_t(j1) * uint32_t(t.img_width) + uint32_t(i0);
+    p.o11 = uint32_t(j1) * uint32_t(t.img_width) + uint32_t(i1);
+    p.mode = 3;
+    return p;
+}
+PTD V3 tex3_value(const TexPlan &p, const DTex &t, float4 t00, float4 t10, float4 t01, float4 t11) {
+    if (p.mode == 1) return mk3(t.c0[0], t.c0[1], t.c0[2]);
+    if (p.mode == 2) return mk3(t.c1[0], t.c1[1], t.c1[2]);
+    if (p.mode == 3)
+        return mk3(lerp2(t00.x, t10.x, t01.x, t11.x, p.fx, p.fy), lerp2(t00.y, t10.y, t01.y, t11.y, p.fx, p.fy),
+                   lerp2(t00.z, t10.z, t01.z, t11.z, p.fx, p.fy));
+    return splat(0.0f);
+}
+PTD float tex1_value(const TexPlan &p, const DTex &t, float t00, float t10, float t01, float t11) {
+    if (p.mode == 1) return t.c0[0];
+    if (p.mode == 2) return t.c1[0];
+    if (p.mode == 3) return lerp2(t00, t10, t01, t11, p.fx, p.fy);
+    return 0.0f;
+}
+
+// A texture lookup up to (not including) its texel reads: the descriptor is read here and
+// boiled down to what the second half needs, so that it does not stay in registers.
+struct TexReq {
+    TexPlan p;
+    const void *data;  // texels of an image texture
+    V3 cval;           // value of a constant / checkerboard texture (scalar textures: .x)
+};
+PTD TexReq tex_request(const DTex *table, uint32_t count, int id, V2 uv) {
+    TexReq r;
+    r.data = nullptr;
+    r.cval = splat(0.0f);
+    const bool valid = id >= 0 && uint32_t(id) < count;
+    const DTex &t = table[valid ? id : 0];
+    r.p = tex_plan(t, valid && count > 0, uv);
+    if (r.p.mode == 1) r.cval = mk3(t.c0[0], t.c0[1], t.c0[2]);
+    else if (r.p.mode == 2) r.cval = mk3(t.c1[0], t.c1[1], t.c1[2]);
+    else if (r.p.mode == 3) r.data = t.img_data;
+    return r;
+}
+PTD V3 tex3_finish(const TexReq &r, float4 t00, float4 t10, float4 t01, float4 t11) {
+    if (r.p.mode == 3)
+        return mk3(lerp2(t00.x, t10.x, t01.x, t11.x, r.p.fx, r.p.fy), lerp2(t00.y, t10.y, t01.y, t11.y, r.p.fx, r.p.fy),
+                   lerp2(t00.z, t10.z, t01.z, t11.z, r.p.fx, r.p.fy));
+    return r.cval;  // zero when the lookup is invalid
+}
+PTD float tex1_finish(const TexReq &r, float t00, float t10, float t01, float t11) {
+    if (r.p.mode == 3) return lerp2(t00, t10, t01, t11, r.p.fx, r.p.fy);
+    return r.cval.x;
+}
+
+struct AliasPick {  // kernel/sampler.h:57-70, up to the table reads
+    uint32_t i;
+    float y;
+};
+PTD AliasPick alias_begin(uint32_t size, float x) {
+    float scaled = x * float(size);
+    uint32_t i = uint32_t(scaled);
+    if (scaled >= float(size)) {
+        i = size - 1;
+        scaled = float(i);
+    }
+    return AliasPick{i, scaled - float(i)};
+}
+PTD uint32_t alias_end(AliasPick p, float prob_i, uint32_t alias_i) { return (p.y < prob_i) ? p.i : alias_i; }
+
+struct V3x3 {
+    V3 a, b, c;
+};
+PTD V3x3 ld3x3(const float *p, uint32_t i0, uint32_t i1, uint32_t i2) { return V3x3{ld3(p, i0), ld3(p, i1), ld3(p, i2)}; }
 
 // math/tonemap.h:10-14
 PTD float aces(float x) {

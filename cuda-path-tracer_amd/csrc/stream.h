@@ -249,6 +249,9 @@ constexpr uint32_t kFetchChunk = 256;
 #endif
 constexpr int kRefillMin = PT_REFILL_MIN;
 
+// Lanes of the wave for which `pred` holds (the predicate's lane mask is counted directly).
+PTD int count_lanes(bool pred) { return __builtin_popcountll(__builtin_amdgcn_ballot_w64(pred)); }
+
 template <int MODE, bool COUNT, class IO>
 PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, const LaneStack &stk, LaneEvents &ev) {
     Traversal<MODE, COUNT> tr;
@@ -259,7 +262,10 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, con
     uint32_t ray_index = 0;
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform
     bool exhausted = false;                // wave-uniform
-    const uint32_t chunk = (n > kFetchChunk * 2u * gridDim.x) ? kFetchChunk : uint32_t(kWave);
+    // rays per work fetch: large for long streams (the cursor is one address, and same-address
+    // atomics serialise at ~12 ns each), one wave's worth for short ones (load balance)
+    const uint32_t chunk = (n > kFetchChunk * 8u * gridDim.x) ? 4u * kFetchChunk
+                           : (n > kFetchChunk * 2u * gridDim.x) ? kFetchChunk : uint32_t(kWave);
     const char *node_base = reinterpret_cast<const char *>(S.nodes);
     for (;;) {
         const uint64_t idle_mask = __ballot(!active);
@@ -302,8 +308,14 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, con
         // ---- box-test rounds, while enough lanes take part.  The node loads are issued before
         // the pops so that the LDS round trip hides behind them.
         for (;;) {
+#ifdef PT_POP_FIRST
+            if (active && tr.wants_pop()) {
+                PT_PHASE(ev, 3);
+                tr.pop(stk);
+            }
+#endif
             const bool w_int = active && tr.wants_interior();
-            const bool go = __popcll(__ballot(w_int)) >= PT_VOTE_INT;
+            const bool go = count_lanes(w_int) >= PT_VOTE_INT;
             float4 na, nb, nc, nd;
             if (go && w_int) {
                 const float4 *np = reinterpret_cast<const float4 *>(node_base + size_t(tr.cur << 6));
@@ -312,10 +324,12 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, con
                 nc = np[2];
                 nd = np[3];
             }
+#ifndef PT_POP_FIRST
             if (active && tr.wants_pop()) {
                 PT_PHASE(ev, 3);
                 tr.pop(stk);
             }
+#endif
             if (!go) break;
             if (w_int) {
                 PT_PHASE(ev, 0);
@@ -328,10 +342,10 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, con
         const bool w_ent = active && tr.wants_enter();
         const bool w_lvl = active && tr.wants_level();
         const bool w_deep = active && tr.wants_deep_pop();
-        const int n_int = __popcll(__ballot(w_int));
-        int n_tri = __popcll(__ballot(active && tr.wants_triangle()));
-        const int n_ent = __popcll(__ballot(w_ent));
-        const int n_lvl = __popcll(__ballot(w_lvl || w_deep));
+        const int n_int = count_lanes(w_int);
+        int n_tri = count_lanes(active && tr.wants_triangle());
+        const int n_ent = count_lanes(w_ent);
+        const int n_lvl = count_lanes(w_lvl || w_deep);
         const int n_max = max(max(n_int, n_tri), max(n_ent, n_lvl));
         if (n_max == 0) continue;  // only lanes that are still popping
         if (n_int >= PT_VOTE_INT) continue;  // pops brought the box-test loop back above its threshold
@@ -351,7 +365,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, con
                         io.done(ray_index, tr, true);
                     }
                 }
-                n_tri = __popcll(__ballot(active && tr.wants_triangle()));
+                n_tri = count_lanes(active && tr.wants_triangle());
             } while (n_tri >= PT_VOTE_TRI);
         }
         if (n_ent > 0 && (n_ent >= PT_VOTE_RARE || n_ent == n_max)) {

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/sq
 rm -rf $OUT && mkdir -p $OUT
-SHORT="bench.py --steps 3 --warmup 1 --cpu-seconds 0 --spp-steps 0"
+SHORT="bench.py --steps 3 --warmup 1 --cpu-seconds 0 --spp-steps ${SQ_SPP_STEPS:-0}"
 timeout -s KILL 60 rocprofv3 --list-avail > $OUT/avail.txt 2>&1 || true
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/a -- python3 $SHORT > $OUT/a.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_INSTS_SMEM --output-format csv -d $OUT/b -- python3 $SHORT > $OUT/b.log 2>&1
