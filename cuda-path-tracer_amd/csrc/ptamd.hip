@@ -44,21 +44,32 @@ struct pt_ctx {
     std::vector<void *> scene_allocs;
 
     // traversal scratch
-    uint2 *spill = nullptr;
     uint32_t spill_stride = 0;
     uint32_t *cursor = nullptr;  // work-fetch cursor of the batch queries
     DevStats *dev_stats = nullptr;
 
-    // integrator
+    // integrator.  Everything a render pass mutates besides the film exists twice ("lanes"):
+    // consecutive pt_render_batch calls alternate between the lanes and run on the lanes' own
+    // streams, so the latency-bound tail of one pass (late bounces with a few thousand rays
+    // each) overlaps the head of the next.  The film passes stay in submission order.
+    struct Lane {
+        hipStream_t stream = nullptr;
+        PathState paths;
+        std::vector<void *> state_allocs;  // per-path state and queues (re-sized with the batch)
+        uint32_t samples_alloc = 0;        // samples (iterations) the path state can hold in flight
+        BounceCounters *counters = nullptr;
+        uint32_t counters_capacity = 0;  // bounces + 2
+        uint2 *spill = nullptr;          // traversal-stack spill area of this lane's kernels
+        hipEvent_t done = nullptr;       // recorded after the lane's last film pass
+        bool pending = false;            // `done` has been recorded and not yet joined
+    } lane[2];
+    int cur_lane = 0;            // the lane of the last render
+    bool overlap_passes = true;  // off while profiling (events bracket kernels on one stream)
+    hipEvent_t fork_event = nullptr;
     bool integrator_ready = false;
     int width = 0, height = 0;
-    PathState paths;
     std::vector<void *> path_allocs;   // film, counters
-    std::vector<void *> state_allocs;  // per-path state and queues (re-sized with the batch)
-    uint32_t samples_alloc = 0;        // samples (iterations) the path state can hold in flight
     float *film = nullptr;
-    BounceCounters *counters = nullptr;
-    uint32_t counters_capacity = 0;  // bounces + 1
     uint32_t *pinned_word = nullptr;
     int last_render_bounces = 0;
     int last_render_samples = 1;
@@ -177,7 +188,9 @@ struct ScopedEvent {
     pt_ctx *ctx;
     EventPair ev;
     bool active;
-    ScopedEvent(pt_ctx *c, int cls) : ctx(c) { BeginEvent(c, cls, ev, active); }
+    ScopedEvent(pt_ctx *c, int cls) : ctx(c), active(false) {  // null context: no timing
+        if (c) BeginEvent(c, cls, ev, active);
+    }
     ~ScopedEvent() { EndEvent(ctx, ev, active); }
 };
 
@@ -298,10 +311,34 @@ void FillCamera(DCamera &c, const pt_camera &h) {
     c.right = V3{h.right[0], h.right[1], h.right[2]};
 }
 
+// Makes ctx->stream wait for the render passes still running on the lanes' streams.
+hipError_t Join(pt_ctx *ctx) {
+    for (pt_ctx::Lane &l : ctx->lane) {
+        if (!l.pending) continue;
+        const hipError_t e = hipStreamWaitEvent(ctx->stream, l.done, 0);
+        if (e != hipSuccess) return e;
+        l.pending = false;
+    }
+    return hipSuccess;
+}
+// Host waits for everything the context has in flight.
+hipError_t SyncAll(pt_ctx *ctx) {
+    const hipError_t e = Join(ctx);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(ctx->stream);
+}
+
+int EnsureLaneSpill(pt_ctx *ctx, pt_ctx::Lane &l) {
+    if (l.spill) return PT_OK;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&l.spill), size_t(ctx->spill_stride) * kSpillDepth * sizeof(uint2)));
+    return PT_OK;
+}
+
 int EnsureScratch(pt_ctx *ctx) {
-    if (ctx->spill) return PT_OK;
+    if (ctx->cursor) return PT_OK;
     ctx->spill_stride = ctx->grid_blocks * kWave;
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->spill), size_t(ctx->spill_stride) * kSpillDepth * sizeof(uint2)));
+    const int st = EnsureLaneSpill(ctx, ctx->lane[0]);
+    if (st != PT_OK) return st;
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->cursor), 256));
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->dev_stats), sizeof(DevStats)));
     HIP_TRY(ctx, hipMemsetAsync(ctx->dev_stats, 0, sizeof(DevStats), ctx->stream));
@@ -328,7 +365,7 @@ int pt_ctx_create(int device, pt_ctx **out) {
     pt_ctx *ctx = new pt_ctx();
     ctx->device = device;
     std::memset(&ctx->scene, 0, sizeof(ctx->scene));
-    std::memset(&ctx->paths, 0, sizeof(ctx->paths));
+    for (pt_ctx::Lane &l : ctx->lane) std::memset(&l.paths, 0, sizeof(l.paths));
     std::memset(&ctx->stats, 0, sizeof(ctx->stats));
     DeviceGuard guard(device);
     hipDeviceProp_t prop;
@@ -352,6 +389,16 @@ int pt_ctx_create(int device, pt_ctx **out) {
         return Fail(nullptr, PT_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     ctx->stream = ctx->own_stream;
+    bool ok = hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming) == hipSuccess;
+    for (pt_ctx::Lane &l : ctx->lane) {
+        ok = ok && hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&l.done, hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) {
+        pt_ctx_destroy(ctx);
+        return Fail(nullptr, PT_ERR_DEVICE, "could not create the render streams");
+    }
+    if (const char *v = getenv("PTAMD_OVERLAP_PASSES")) ctx->overlap_passes = atoi(v) != 0;  // tuning aid
     *out = ctx;
     return PT_OK;
 }
@@ -359,7 +406,7 @@ int pt_ctx_create(int device, pt_ctx **out) {
 void pt_ctx_destroy(pt_ctx *ctx) {
     if (!ctx) return;
     DeviceGuard guard(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)SyncAll(ctx);
     DrainEvents(ctx);
     for (EventPair &ev : ctx->free_events) {
         (void)hipEventDestroy(ev.start);
@@ -367,7 +414,12 @@ void pt_ctx_destroy(pt_ctx *ctx) {
     }
     pt_integrator_destroy(ctx);
     FreeScene(ctx);
-    if (ctx->spill) (void)hipFree(ctx->spill);
+    for (pt_ctx::Lane &l : ctx->lane) {
+        if (l.spill) (void)hipFree(l.spill);
+        if (l.stream) (void)hipStreamDestroy(l.stream);
+        if (l.done) (void)hipEventDestroy(l.done);
+    }
+    if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
     if (ctx->cursor) (void)hipFree(ctx->cursor);
     if (ctx->dev_stats) (void)hipFree(ctx->dev_stats);
     if (ctx->pinned_word) (void)hipHostFree(ctx->pinned_word);
@@ -378,7 +430,7 @@ void pt_ctx_destroy(pt_ctx *ctx) {
 int pt_set_stream(pt_ctx *ctx, void *hip_stream) {
     if (!ctx) return PT_ERR_INVALID;
     DeviceGuard guard(ctx->device);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, SyncAll(ctx));
     ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
     return PT_OK;
 }
@@ -386,7 +438,7 @@ int pt_set_stream(pt_ctx *ctx, void *hip_stream) {
 int pt_synchronize(pt_ctx *ctx) {
     if (!ctx) return PT_ERR_INVALID;
     DeviceGuard guard(ctx->device);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, SyncAll(ctx));
     return PT_OK;
 }
 
@@ -416,7 +468,7 @@ int pt_set_trace_mode(pt_ctx *ctx, int mode) {
 int pt_reset_stats(pt_ctx *ctx) {
     if (!ctx) return PT_ERR_INVALID;
     DeviceGuard guard(ctx->device);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, SyncAll(ctx));
     DrainEvents(ctx);
     std::memset(&ctx->stats, 0, sizeof(ctx->stats));
     if (ctx->dev_stats) HIP_TRY(ctx, hipMemsetAsync(ctx->dev_stats, 0, sizeof(DevStats), ctx->stream));
@@ -426,7 +478,7 @@ int pt_reset_stats(pt_ctx *ctx) {
 int pt_get_stats(pt_ctx *ctx, pt_stats *out) {
     if (!ctx || !out) return PT_ERR_INVALID;
     DeviceGuard guard(ctx->device);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, SyncAll(ctx));
     DrainEvents(ctx);
     if (ctx->dev_stats) {
         DevStats ds;
@@ -435,9 +487,10 @@ int pt_get_stats(pt_ctx *ctx, pt_stats *out) {
         ctx->stats.stack_drops = ds.drops;
         ctx->stats.nan_pixels = ds.nan_pixels;
     }
-    if (ctx->integrator_ready && ctx->counters && ctx->last_render_bounces > 0) {
+    const BounceCounters *last_counters = ctx->lane[ctx->cur_lane].counters;
+    if (ctx->integrator_ready && last_counters && ctx->last_render_bounces > 0) {
         std::vector<BounceCounters> bc(size_t(ctx->last_render_bounces) + 1);
-        HIP_TRY(ctx, hipMemcpy(bc.data(), ctx->counters, bc.size() * sizeof(BounceCounters), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(bc.data(), last_counters, bc.size() * sizeof(BounceCounters), hipMemcpyDeviceToHost));
         ctx->stats.closest_rays = 0;
         ctx->stats.shadow_rays = 0;
         ctx->stats.bounces_run = 0;
@@ -460,7 +513,7 @@ int pt_get_stats(pt_ctx *ctx, pt_stats *out) {
 int pt_scene_free(pt_ctx *ctx) {
     if (!ctx) return PT_ERR_INVALID;
     DeviceGuard guard(ctx->device);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, SyncAll(ctx));
     return FreeScene(ctx);
 }
 
@@ -477,7 +530,7 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
     DeviceGuard guard(ctx->device);
     int st = Validate(ctx, d);
     if (st != PT_OK) return st;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, SyncAll(ctx));
     FreeScene(ctx);
     st = EnsureScratch(ctx);
     if (st != PT_OK) return st;
@@ -805,41 +858,43 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
 }
 
 // ------------------------------------------------------------------ integrator
-// (Re)allocates the per-path state for `samples` iterations in flight at the context's resolution.
-static int EnsurePaths(pt_ctx *ctx, uint32_t samples) {
-    if (ctx->samples_alloc >= samples) return PT_OK;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    FreeAll(ctx->state_allocs);
-    ctx->samples_alloc = 0;
+// (Re)allocates a lane's per-path state for `samples` iterations in flight at the context's resolution.
+static int EnsurePaths(pt_ctx *ctx, pt_ctx::Lane &l, uint32_t samples) {
+    if (l.samples_alloc >= samples) return PT_OK;
+    HIP_TRY(ctx, SyncAll(ctx));
+    FreeAll(l.state_allocs);
+    l.samples_alloc = 0;
     const uint32_t tiles = uint32_t((ctx->width + 7) / 8) * uint32_t((ctx->height + 7) / 8);
     const size_t per_sample = size_t(tiles) * 64;
     const size_t cap = per_sample * samples;
     if (cap >= (1ull << 31)) return Fail(ctx, PT_ERR_LIMIT, "%u samples in flight at %dx%d exceed 2^31 path slots", samples, ctx->width, ctx->height);
-    PathState &P = ctx->paths;
+    PathState &P = l.paths;
     std::memset(&P, 0, sizeof(P));
     int st = PT_OK;
-#define AL(field) if ((st = Alloc(ctx, ctx->state_allocs, cap, &P.field)) != PT_OK) return st
+#define AL(field) if ((st = Alloc(ctx, l.state_allocs, cap, &P.field)) != PT_OK) return st
     AL(ray_o); AL(ray_d); AL(thr); AL(accum); AL(last_pos); AL(rng); AL(hit); AL(hit_inst); AL(sh_o); AL(sh_d); AL(sh_c); AL(sh_q);
     AL(ext_q[0]); AL(ext_q[1]);
     for (int k = 0; k < kNumClasses; ++k) AL(class_q[k]);
 #undef AL
     P.capacity = uint32_t(cap);
     P.slots_per_sample = uint32_t(per_sample);
-    ctx->samples_alloc = samples;
+    l.samples_alloc = samples;
     return PT_OK;
 }
 
 int pt_integrator_destroy(pt_ctx *ctx) {
     if (!ctx) return PT_ERR_INVALID;
     DeviceGuard guard(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)SyncAll(ctx);
     FreeAll(ctx->path_allocs);
-    FreeAll(ctx->state_allocs);
-    ctx->samples_alloc = 0;
+    for (pt_ctx::Lane &l : ctx->lane) {
+        FreeAll(l.state_allocs);
+        l.samples_alloc = 0;
+        l.counters = nullptr;
+        l.counters_capacity = 0;
+        std::memset(&l.paths, 0, sizeof(l.paths));
+    }
     ctx->film = nullptr;
-    ctx->counters = nullptr;
-    ctx->counters_capacity = 0;
-    std::memset(&ctx->paths, 0, sizeof(ctx->paths));
     ctx->integrator_ready = false;
     ctx->width = ctx->height = 0;
     return PT_OK;
@@ -857,7 +912,8 @@ int pt_integrator_init(pt_ctx *ctx, int width, int height) {
     HIP_TRY(ctx, hipMemsetAsync(ctx->film, 0, size_t(width) * height * 3 * sizeof(float), ctx->stream));
     ctx->width = width;
     ctx->height = height;
-    if ((st = EnsurePaths(ctx, 1)) != PT_OK) return st;
+    if ((st = EnsurePaths(ctx, ctx->lane[0], 1)) != PT_OK) return st;
+    ctx->cur_lane = 0;
     ctx->integrator_ready = true;
     return PT_OK;
 }
@@ -869,33 +925,38 @@ int pt_integrator_reset(pt_ctx *ctx, int width, int height) {
     if (!ctx->integrator_ready) return Fail(ctx, PT_ERR_STATE, "pt_integrator_reset before pt_integrator_init");
     if (width != ctx->width || height != ctx->height) return Fail(ctx, PT_ERR_INVALID, "reset resolution differs from the integrator's");
     DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, Join(ctx));
     HIP_TRY(ctx, hipMemsetAsync(ctx->film, 0, size_t(width) * height * 3 * sizeof(float), ctx->stream));
     return PT_OK;
 }
 
-static int EnsureCounters(pt_ctx *ctx, uint32_t bounces) {
-    if (ctx->counters_capacity >= bounces + 2) return PT_OK;
+static int EnsureCounters(pt_ctx *ctx, pt_ctx::Lane &l, uint32_t bounces) {
+    if (l.counters_capacity >= bounces + 2) return PT_OK;
     BounceCounters *c = nullptr;
     int st = Alloc(ctx, ctx->path_allocs, size_t(bounces) + 2, &c);
     if (st != PT_OK) return st;
-    ctx->counters = c;
-    ctx->counters_capacity = bounces + 2;
+    l.counters = c;
+    l.counters_capacity = bounces + 2;
     return PT_OK;
 }
 
-// Runs generate + `bounces` bounce rounds of iteration `iteration` (no film pass).
-static int RunBounces(pt_ctx *ctx, int width, int height, int iteration, int samples, int bounces, bool shade_last) {
+// Runs generate + `bounces` bounce rounds of iteration `iteration` (no film pass) with lane `l`'s
+// state on `stream`.
+static int RunBounces(pt_ctx *ctx, pt_ctx::Lane &l, hipStream_t stream, int width, int height, int iteration, int samples, int bounces,
+                      bool shade_last) {
     const DScene &S = ctx->scene;
-    int st = EnsurePaths(ctx, uint32_t(samples));
+    int st = EnsurePaths(ctx, l, uint32_t(samples));
     if (st != PT_OK) return st;
-    PathState &P = ctx->paths;
-    st = EnsureCounters(ctx, S.max_depth);
+    if ((st = EnsureLaneSpill(ctx, l)) != PT_OK) return st;
+    PathState &P = l.paths;
+    st = EnsureCounters(ctx, l, S.max_depth);
     if (st != PT_OK) return st;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, size_t(ctx->counters_capacity) * sizeof(BounceCounters), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(l.counters, 0, size_t(l.counters_capacity) * sizeof(BounceCounters), stream));
     const uint32_t tiles = P.slots_per_sample / 64 * uint32_t(samples);
+    const bool timed = stream == ctx->stream;  // kernel timing events bracket launches on ctx->stream only
     {
-        ScopedEvent ev(ctx, EV_GENERATE);
-        hipLaunchKernelGGL(k_generate, dim3(tiles), dim3(kWave), 0, ctx->stream, S, P, ctx->counters, iteration, width, height);
+        ScopedEvent ev(timed ? ctx : nullptr, EV_GENERATE);
+        hipLaunchKernelGGL(k_generate, dim3(tiles), dim3(kWave), 0, stream, S, P, l.counters, iteration, width, height);
     }
     const dim3 grid(ctx->grid_blocks), block(kWave);
     ctx->last_render_bounces = bounces;
@@ -903,21 +964,21 @@ static int RunBounces(pt_ctx *ctx, int width, int height, int iteration, int sam
         const bool last = (b == bounces - 1);
         if (last && !shade_last) break;
         {
-            ScopedEvent ev(ctx, EV_CLOSEST);
-            hipLaunchKernelGGL(k_extend, grid, block, 0, ctx->stream, S, P, ctx->counters, b, width, height, ctx->spill, ctx->spill_stride, ctx->dev_stats);
+            ScopedEvent ev(timed ? ctx : nullptr, EV_CLOSEST);
+            hipLaunchKernelGGL(k_extend, grid, block, 0, stream, S, P, l.counters, b, width, height, l.spill, ctx->spill_stride, ctx->dev_stats);
         }
         {
-            ScopedEvent ev(ctx, EV_SHADE);
-            hipLaunchKernelGGL(k_shade, grid, block, 0, ctx->stream, S, P, ctx->counters, b);
+            ScopedEvent ev(timed ? ctx : nullptr, EV_SHADE);
+            hipLaunchKernelGGL(k_shade, grid, block, 0, stream, S, P, l.counters, b);
         }
         {
-            ScopedEvent ev(ctx, EV_ANY);
-            hipLaunchKernelGGL(k_shadow, grid, block, 0, ctx->stream, S, P, ctx->counters, b, ctx->spill, ctx->spill_stride, ctx->dev_stats);
+            ScopedEvent ev(timed ? ctx : nullptr, EV_ANY);
+            hipLaunchKernelGGL(k_shadow, grid, block, 0, stream, S, P, l.counters, b, l.spill, ctx->spill_stride, ctx->dev_stats);
         }
         // long depth limits: stop launching once the extension queue has drained
         if ((b & 7) == 7 && b + 1 < bounces) {
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned_word, &ctx->counters[b + 1].ext_count, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned_word, &l.counters[b + 1].ext_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(ctx, hipStreamSynchronize(stream));
             if (*ctx->pinned_word == 0) {
                 ctx->last_render_bounces = b + 1;
                 break;
@@ -938,24 +999,46 @@ int pt_render_batch(pt_ctx *ctx, int width, int height, int iteration, int sampl
         return Fail(ctx, PT_ERR_INVALID, "render resolution differs from the camera's");
     if (iteration < 0) return Fail(ctx, PT_ERR_INVALID, "iteration must be >= 0");
     DeviceGuard guard(ctx->device);
-    if (iteration == 0) HIP_TRY(ctx, hipMemsetAsync(ctx->film, 0, size_t(width) * height * 3 * sizeof(float), ctx->stream));  // path_trace.cu:438-439
-    int st = RunBounces(ctx, width, height, iteration, samples, int(ctx->scene.max_depth), true);
+    // Serial mode runs on ctx->stream with lane 0.  Overlapped mode alternates the lanes: the pass
+    // starts after everything submitted to ctx->stream so far, shares nothing mutable with the
+    // pass on the other lane except the film, and takes its turn at the film after that pass.
+    const bool overlap = ctx->overlap_passes && !ctx->profiling;
+    const int li = overlap ? (ctx->cur_lane ^ 1) : 0;
+    pt_ctx::Lane &l = ctx->lane[li], &other = ctx->lane[li ^ 1];
+    hipStream_t stream = ctx->stream;
+    if (overlap) {
+        stream = l.stream;
+        HIP_TRY(ctx, hipEventRecord(ctx->fork_event, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->fork_event, 0));
+    } else {
+        HIP_TRY(ctx, Join(ctx));
+    }
+    if (iteration == 0) {  // path_trace.cu:438-439
+        if (overlap && other.pending) HIP_TRY(ctx, hipStreamWaitEvent(stream, other.done, 0));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->film, 0, size_t(width) * height * 3 * sizeof(float), stream));
+    }
+    int st = RunBounces(ctx, l, stream, width, height, iteration, samples, int(ctx->scene.max_depth), true);
     if (st != PT_OK) return st;
+    if (overlap && other.pending) HIP_TRY(ctx, hipStreamWaitEvent(stream, other.done, 0));  // film passes in submission order
     {
-        ScopedEvent ev(ctx, EV_FILM);
-        hipLaunchKernelGGL(k_film, dim3(ctx->paths.slots_per_sample / 64), dim3(kWave), 0, ctx->stream, ctx->paths, ctx->film, width, height, samples,
-                           ctx->dev_stats);
+        ScopedEvent ev(overlap ? nullptr : ctx, EV_FILM);
+        hipLaunchKernelGGL(k_film, dim3(l.paths.slots_per_sample / 64), dim3(kWave), 0, stream, l.paths, ctx->film, width, height, samples, ctx->dev_stats);
     }
     if (rgba_device) {
         const uint32_t n = uint32_t(width) * uint32_t(height);
-        hipLaunchKernelGGL(k_tonemap, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->film, rgba_device, width, height, iteration + samples);
+        hipLaunchKernelGGL(k_tonemap, dim3((n + 255) / 256), dim3(256), 0, stream, ctx->film, rgba_device, width, height, iteration + samples);
     }
     HIP_TRY(ctx, hipGetLastError());
+    if (overlap) {
+        HIP_TRY(ctx, hipEventRecord(l.done, stream));
+        l.pending = true;
+    }
+    ctx->cur_lane = li;
     ctx->last_render_samples = samples;
     if (getenv("PTAMD_DEBUG_QUEUES")) {  // tuning aid: per-bounce queue sizes of this pass on stderr
         std::vector<BounceCounters> h(size_t(ctx->last_render_bounces) + 1);
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipMemcpy(h.data(), ctx->counters, h.size() * sizeof(BounceCounters), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, SyncAll(ctx));
+        HIP_TRY(ctx, hipMemcpy(h.data(), l.counters, h.size() * sizeof(BounceCounters), hipMemcpyDeviceToHost));
         for (size_t b = 0; b < h.size(); ++b)
             fprintf(stderr, "[ptamd] bounce %zu: extend %u, classes %u %u %u %u %u, shadow %u\n", b, h[b].ext_count, h[b].class_count[0],
                     h[b].class_count[1], h[b].class_count[2], h[b].class_count[3], h[b].class_count[4], h[b].shadow_count);
@@ -971,7 +1054,7 @@ int pt_render(pt_ctx *ctx, int width, int height, int iteration, uint8_t *rgba_d
     int st = pt_render_async(ctx, width, height, iteration, rgba_device);
     if (st != PT_OK) return st;
     DeviceGuard guard(ctx->device);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // path_trace.cu:481
+    HIP_TRY(ctx, SyncAll(ctx));  // path_trace.cu:481
     return PT_OK;
 }
 
@@ -980,7 +1063,7 @@ int pt_film_download(pt_ctx *ctx, float *rgb_host) {
     if (!ctx->integrator_ready) return Fail(ctx, PT_ERR_STATE, "no film: integrator not initialised");
     DeviceGuard guard(ctx->device);
     HIP_TRY(ctx, hipMemcpyAsync(rgb_host, ctx->film, size_t(ctx->width) * ctx->height * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, SyncAll(ctx));
     return PT_OK;
 }
 
@@ -989,7 +1072,7 @@ int pt_film_copy_to_device(pt_ctx *ctx, float *rgb_device) {
     if (!ctx->integrator_ready) return Fail(ctx, PT_ERR_STATE, "no film: integrator not initialised");
     DeviceGuard guard(ctx->device);
     HIP_TRY(ctx, hipMemcpyAsync(rgb_device, ctx->film, size_t(ctx->width) * ctx->height * 3 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, SyncAll(ctx));
     return PT_OK;
 }
 
@@ -998,7 +1081,7 @@ int pt_film_copy_from_device(pt_ctx *ctx, const float *rgb_device) {
     if (!ctx->integrator_ready) return Fail(ctx, PT_ERR_STATE, "no film: integrator not initialised");
     DeviceGuard guard(ctx->device);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->film, rgb_device, size_t(ctx->width) * ctx->height * 3 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, SyncAll(ctx));
     return PT_OK;
 }
 
@@ -1013,7 +1096,7 @@ int pt_tonemap(pt_ctx *ctx, const float *film_device, int width, int height, int
     const uint32_t n = uint32_t(width) * uint32_t(height);
     hipLaunchKernelGGL(k_tonemap, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, film_device, rgba_device, width, height, iterations);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, SyncAll(ctx));
     return PT_OK;
 }
 
@@ -1032,12 +1115,13 @@ int pt_trace_closest(pt_ctx *ctx, const pt_ray *rays, size_t n, pt_hit *hits) {
     if (st != PT_OK || n == 0) return st;
     if ((reinterpret_cast<uintptr_t>(hits) & 15u) != 0) return Fail(ctx, PT_ERR_INVALID, "hit buffer must be 16-byte aligned");
     DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, Join(ctx));  // lane 0's spill area is shared with render passes
     HIP_TRY(ctx, hipMemsetAsync(ctx->cursor, 0, sizeof(uint32_t), ctx->stream));
     const uint32_t blocks = uint32_t(std::min<size_t>(ctx->grid_blocks, (n + kWave - 1) / kWave));
     {
         ScopedEvent ev(ctx, EV_CLOSEST);
         hipLaunchKernelGGL(k_trace_closest<false>, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor,
-                           ctx->spill, ctx->spill_stride, ctx->dev_stats, static_cast<TraceCounters *>(nullptr));
+                           ctx->lane[0].spill, ctx->spill_stride, ctx->dev_stats, static_cast<TraceCounters *>(nullptr));
     }
     HIP_TRY(ctx, hipGetLastError());
     return PT_OK;
@@ -1047,11 +1131,12 @@ int pt_trace_any(pt_ctx *ctx, const pt_ray *rays, size_t n, uint8_t *occluded) {
     int st = CheckQuery(ctx, rays, occluded, n);
     if (st != PT_OK || n == 0) return st;
     DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, Join(ctx));  // lane 0's spill area is shared with render passes
     HIP_TRY(ctx, hipMemsetAsync(ctx->cursor, 0, sizeof(uint32_t), ctx->stream));
     const uint32_t blocks = uint32_t(std::min<size_t>(ctx->grid_blocks, (n + kWave - 1) / kWave));
     {
         ScopedEvent ev(ctx, EV_ANY);
-        hipLaunchKernelGGL(k_trace_any, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), occluded, ctx->cursor, ctx->spill,
+        hipLaunchKernelGGL(k_trace_any, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), occluded, ctx->cursor, ctx->lane[0].spill,
                            ctx->spill_stride, ctx->dev_stats);
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -1075,9 +1160,10 @@ int pt_trace_closest_counted(pt_ctx *ctx, const pt_ray *rays, size_t n, pt_hit *
     if (st != PT_OK || n == 0) return st;
     if (!counters4) return Fail(ctx, PT_ERR_INVALID, "null counter buffer");
     DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, Join(ctx));  // lane 0's spill area is shared with render passes
     HIP_TRY(ctx, hipMemsetAsync(ctx->cursor, 0, sizeof(uint32_t), ctx->stream));
     const uint32_t blocks = uint32_t(std::min<size_t>(ctx->grid_blocks, (n + kWave - 1) / kWave));
-    hipLaunchKernelGGL(k_trace_closest<true>, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->spill,
+    hipLaunchKernelGGL(k_trace_closest<true>, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->lane[0].spill,
                        ctx->spill_stride, ctx->dev_stats, reinterpret_cast<TraceCounters *>(counters4));
     HIP_TRY(ctx, hipGetLastError());
     return PT_OK;
@@ -1154,20 +1240,23 @@ int pt_capture_bounce_rays(pt_ctx *ctx, int width, int height, int iteration, in
     if (bounce < 0 || uint32_t(bounce) >= ctx->scene.max_depth) return Fail(ctx, PT_ERR_INVALID, "bounce %d outside [0, max_depth)", bounce);
     if (!rays_device || (reinterpret_cast<uintptr_t>(rays_device) & 15u)) return Fail(ctx, PT_ERR_INVALID, "ray buffer must be a 16-byte aligned device pointer");
     DeviceGuard guard(ctx->device);
-    int st = RunBounces(ctx, width, height, iteration, 1, bounce + 1, false);
+    HIP_TRY(ctx, Join(ctx));
+    pt_ctx::Lane &l = ctx->lane[0];
+    ctx->cur_lane = 0;
+    int st = RunBounces(ctx, l, ctx->stream, width, height, iteration, 1, bounce + 1, false);
     ctx->last_render_samples = 1;
     if (st != PT_OK) return st;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned_word, &ctx->counters[bounce].ext_count, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned_word, &l.counters[bounce].ext_count, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, SyncAll(ctx));
     // bounce 0 streams every path slot (padded to 8x8 tiles) and writes the W*H camera rays in pixel order
     const size_t launch_n = *ctx->pinned_word;
     const size_t produced = bounce == 0 ? size_t(width) * size_t(height) : launch_n;
     if (produced > capacity) return Fail(ctx, PT_ERR_LIMIT, "capture buffer holds %zu rays, %zu needed", capacity, produced);
     if (launch_n > 0) {
-        hipLaunchKernelGGL(k_gather_rays, dim3(uint32_t((launch_n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->paths, ctx->counters, bounce, rays_device,
+        hipLaunchKernelGGL(k_gather_rays, dim3(uint32_t((launch_n + 255) / 256)), dim3(256), 0, ctx->stream, l.paths, l.counters, bounce, rays_device,
                            uint32_t(capacity), width, height);
         HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, SyncAll(ctx));
     }
     *count = produced;
     return PT_OK;
