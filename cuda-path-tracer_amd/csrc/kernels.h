@@ -345,7 +345,7 @@ struct ExtendIO {
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&bc->class_count[k], staged[k]);
             base = __shfl(base, 0, 64);
-            if (lane < staged[k]) P.class_q[k][base + lane] = stage[k * kStageCap + lane];
+            for (uint32_t i = lane; i < staged[k]; i += kWave) P.class_q[k][base + i] = stage[k * kStageCap + i];  // up to kStageFlush - 1 entries
             staged[k] = 0;
         }
     }
