@@ -111,6 +111,7 @@ struct ClosestIO {
         hp[1] = make_float4(as_f(uint32_t(hit ? tr.hit.inst : -1)), as_f(uint32_t(mat)), 0.0f, 0.0f);
         if (COUNT) counters[i] = tr.ctr;
     }
+    PTD bool has_pending() const { return false; }
     PTD void flush() const {}
     PTD void finish() const {}
 };
@@ -118,11 +119,10 @@ struct ClosestIO {
 template <bool COUNT>
 __global__ __launch_bounds__(64) void k_trace_closest(DScene S, const pt_ray *rays, uint32_t n, pt_hit *hits, uint32_t *cursor,
                                                       uint2 *spill, uint32_t spill_stride, DevStats *stats, TraceCounters *counters) {
-    __shared__ unsigned long long lds[kLdsDepth * kWave];
-    const uint32_t lane = threadIdx.x;
-    const LaneStack stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
     LaneEvents ev;
     ClosestIO<COUNT> io{S, rays, hits, counters};
+    __shared__ unsigned long long lds[kLdsDepth * kWave];
+    const LaneStack stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
     trace_stream<MODE_CLOSEST, COUNT>(S, io, n, cursor, stk, ev);
     flush_events(stats, ev);
 }
@@ -139,17 +139,17 @@ struct AnyIO {
         return true;
     }
     PTD void done(uint32_t i, const Traversal<MODE_ANY, false> &, bool hit) const { occluded[i] = hit ? 1 : 0; }
+    PTD bool has_pending() const { return false; }
     PTD void flush() const {}
     PTD void finish() const {}
 };
 
 __global__ __launch_bounds__(64) void k_trace_any(DScene S, const pt_ray *rays, uint32_t n, uint8_t *occluded, uint32_t *cursor,
                                                   uint2 *spill, uint32_t spill_stride, DevStats *stats) {
-    __shared__ unsigned long long lds[kLdsDepth * kWave];
-    const uint32_t lane = threadIdx.x;
-    const LaneStack stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
     LaneEvents ev;
     AnyIO io{rays, occluded};
+    __shared__ unsigned long long lds[kLdsDepth * kWave];
+    const LaneStack stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
     trace_stream<MODE_ANY, false>(S, io, n, cursor, stk, ev);
     flush_events(stats, ev);
 }
@@ -271,8 +271,8 @@ struct ExtendIO {
     bool pending = false;
     uint32_t pend_slot = 0;
     int pend_cls = 0;
-    uint32_t slot = 0;
     PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax) {
+        uint32_t slot;
         if (queue) {
             slot = queue[i];
         } else {
@@ -286,7 +286,9 @@ struct ExtendIO {
         tmax = FLT_MAX;
         return true;
     }
-    PTD void done(uint32_t, const Traversal<MODE_CLOSEST, false> &tr, bool hit) {
+    PTD bool has_pending() const { return pending; }
+    PTD void done(uint32_t i, const Traversal<MODE_CLOSEST, false> &tr, bool hit) {
+        const uint32_t slot = queue ? queue[i] : i;  // a lane may trace several rays at once: nothing is kept from load()
         P.hit_inst[slot] = hit ? tr.hit.inst : -1;
         if (!hit) {
             const float4 t = P.thr[slot];
@@ -353,14 +355,13 @@ struct ExtendIO {
 
 __global__ __launch_bounds__(64) void k_extend(DScene S, PathState P, BounceCounters *cnt, int bounce, int width, int height, uint2 *spill,
                                                uint32_t spill_stride, DevStats *stats) {
-    __shared__ unsigned long long lds[kLdsDepth * kWave];
-    const uint32_t lane = threadIdx.x;
-    const LaneStack stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
     BounceCounters *bc = cnt + bounce;
     LaneEvents ev;
     __shared__ uint32_t stage[kNumClasses * kStageCap];
     ExtendIO io{S, P, bc, bounce == 0 ? nullptr : P.ext_q[bounce & 1], width, height};
     io.stage = stage;
+    __shared__ unsigned long long lds[kLdsDepth * kWave];
+    const LaneStack stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
     trace_stream<MODE_CLOSEST, false>(S, io, bc->ext_count, &bc->cur_extend, stk, ev);
     flush_events(stats, ev);
 }
@@ -699,37 +700,36 @@ __global__ __launch_bounds__(64) void k_shade(DScene S, PathState P, BounceCount
 // t_max = dist - 1e-4; an unoccluded sample adds its contribution to the path's radiance.
 struct ShadowIO {
     const PathState &P;
-    uint32_t slot = 0;
-    float4 contrib;
     PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax) {
-        slot = P.sh_q[i];
+        const uint32_t slot = P.sh_q[i];
         const float4 so = P.sh_o[slot], sd = P.sh_d[slot];
-        contrib = P.sh_c[slot];
         o = mk3(so.x, so.y, so.z);
         d = mk3(sd.x, sd.y, sd.z);
         tmax = so.w;
         return true;
     }
-    PTD void done(uint32_t, const Traversal<MODE_ANY, false> &, bool occluded) const {
+    PTD void done(uint32_t i, const Traversal<MODE_ANY, false> &, bool occluded) const {
         if (occluded) return;
+        const uint32_t slot = P.sh_q[i];
+        const float4 contrib = P.sh_c[slot];
         float4 a = P.accum[slot];
         a.x += contrib.x;
         a.y += contrib.y;
         a.z += contrib.z;
         P.accum[slot] = a;
     }
+    PTD bool has_pending() const { return false; }
     PTD void flush() const {}
     PTD void finish() const {}
 };
 
 __global__ __launch_bounds__(64) void k_shadow(DScene S, PathState P, BounceCounters *cnt, int bounce, uint2 *spill,
                                                uint32_t spill_stride, DevStats *stats) {
-    __shared__ unsigned long long lds[kLdsDepth * kWave];
-    const uint32_t lane = threadIdx.x;
-    const LaneStack stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
     BounceCounters *bc = cnt + bounce;
     LaneEvents ev;
     ShadowIO io{P};
+    __shared__ unsigned long long lds[kLdsDepth * kWave];
+    const LaneStack stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
     trace_stream<MODE_ANY, false>(S, io, bc->shadow_count, &bc->cur_shadow, stk, ev);
     flush_events(stats, ev);
 }
