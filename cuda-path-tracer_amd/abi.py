@@ -116,6 +116,17 @@ class Stats(C.Structure):
         ("n_film", C.c_uint32)]
 
 
+class IntegratorState(C.Structure):
+    """pt_integrator_state (IntegratorState, kernel/device_types.h:26-34)."""
+    _fields_ = [("visualize_bvh", C.c_int32), ("bvh_visualize_type", C.c_int32), ("bvh_visualize_depth", C.c_int32),
+                ("debug_mode", C.c_int32)]
+
+
+# DebugVisualizeMode / BVH_VisualizeMode, kernel/device_types.h:10-24
+(PT_DEBUG_NONE, PT_DEBUG_GEOMETRIC_NORMALS, PT_DEBUG_ALBEDO, PT_DEBUG_UV, PT_DEBUG_DEPTH, PT_DEBUG_METALLIC,
+ PT_DEBUG_ROUGHNESS) = range(7)
+PT_BVH_BOUNDS_HIT, PT_BVH_TLAS, PT_BVH_TRIANGLES_HIT = range(3)
+
 assert C.sizeof(Material) == 16 and C.sizeof(Texture1) == 32 and C.sizeof(Texture3) == 44
 
 # Every symbol the two public headers declare (tests check that the library exports all of them).
@@ -126,7 +137,7 @@ PT_SYMBOLS = [
     "pt_render_async", "pt_render_batch", "pt_film_download", "pt_film_copy_to_device", "pt_film_copy_from_device", "pt_tonemap",
     "pt_trace_closest", "pt_trace_any", "pt_resolve_hits", "pt_trace_closest_counted", "pt_trace_closest_host",
     "pt_trace_any_host", "pt_resolve_hits_host", "pt_generate_incoherent_rays", "pt_capture_bounce_rays",
-    "pt_set_trace_mode"]
+    "pt_set_trace_mode", "pt_debug_render"]
 PTH_SYMBOLS = [
     "pth_last_error", "pth_transform_matrix", "pth_matrix_derive", "pth_matrix_mul", "pth_gltf_local_matrix",
     "pth_alias_build", "pth_camera_make", "pth_bvh_build", "pth_bvh_sizes", "pth_bvh_get", "pth_bvh_free",
@@ -134,7 +145,7 @@ PTH_SYMBOLS = [
     "pth_scene_add_material", "pth_scene_add_texture1", "pth_scene_add_texture3", "pth_scene_add_image",
     "pth_scene_new_blas_index", "pth_scene_add_instance", "pth_scene_finalize", "pth_scene_get_desc",
     "pth_scene_update_device", "pth_integrator_create", "pth_integrator_destroy", "pth_integrator_init",
-    "pth_integrator_resize", "pth_integrator_reset", "pth_integrator_render", "pth_save_png", "pth_save_hdr"]
+    "pth_integrator_resize", "pth_integrator_reset", "pth_integrator_render", "pth_debug_render", "pth_save_png", "pth_save_hdr"]
 
 _lib = None
 
@@ -195,6 +206,7 @@ def load_library() -> C.CDLL:
         "pt_generate_incoherent_rays": (i32, [vp, vp, sz, u64]),
         "pt_capture_bounce_rays": (i32, [vp, i32, i32, i32, i32, vp, sz, C.POINTER(sz)]),
         "pt_set_trace_mode": (i32, [vp, i32]),
+        "pt_debug_render": (i32, [vp, i32, i32, C.POINTER(IntegratorState), vp, vp]),
         "pth_last_error": (C.c_char_p, []),
         "pth_transform_matrix": (i32, [fp, fp, fp, fp]),
         "pth_matrix_derive": (i32, [fp, fp, fp]),
@@ -226,6 +238,7 @@ def load_library() -> C.CDLL:
         "pth_integrator_resize": (i32, [vp, i32, i32]),
         "pth_integrator_reset": (i32, [vp, i32, i32]),
         "pth_integrator_render": (i32, [vp, i32, i32, vp, vp, i32]),
+        "pth_debug_render": (i32, [vp, i32, i32, vp, C.POINTER(IntegratorState), vp]),
         "pth_save_png": (i32, [C.c_char_p, vp, i32, i32]),
         "pth_save_hdr": (i32, [C.c_char_p, vp, i32, i32, i32]),
     }

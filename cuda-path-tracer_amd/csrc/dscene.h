@@ -105,6 +105,7 @@ struct DCamera {
     float px, py;  // pixel_length
     float focal_length;
     V3 position, front, up, right;
+    float near_plane, far_plane;
 };
 
 struct DScene {

@@ -12,6 +12,7 @@
 
 #include "../../include/ptamd.h"
 #include "kernels.h"
+#include "debug_view.h"
 #ifndef PT_WAVES_PER_CU
 #define PT_WAVES_PER_CU 16  // persistent waves per CU (4 per SIMD)
 #endif
@@ -309,6 +310,8 @@ void FillCamera(DCamera &c, const pt_camera &h) {
     c.front = V3{h.front[0], h.front[1], h.front[2]};
     c.up = V3{h.up[0], h.up[1], h.up[2]};
     c.right = V3{h.right[0], h.right[1], h.right[2]};
+    c.near_plane = h.near_plane;
+    c.far_plane = h.far_plane;
 }
 
 // Makes ctx->stream wait for the render passes still running on the lanes' streams.
@@ -1165,6 +1168,38 @@ int pt_trace_closest_counted(pt_ctx *ctx, const pt_ray *rays, size_t n, pt_hit *
     const uint32_t blocks = uint32_t(std::min<size_t>(ctx->grid_blocks, (n + kWave - 1) / kWave));
     hipLaunchKernelGGL(k_trace_closest<true>, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->lane[0].spill,
                        ctx->spill_stride, ctx->dev_stats, reinterpret_cast<TraceCounters *>(counters4));
+    HIP_TRY(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+// DebugIntegrator::Render, kernel/integrators/debug.cu:198-239: both views in one streamed pass.
+int pt_debug_render(pt_ctx *ctx, int width, int height, const pt_integrator_state *state, float *image_device, uint8_t *rgba_device) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->scene_ready) return Fail(ctx, PT_ERR_STATE, "pt_debug_render before pt_scene_upload");
+    if (!state) return Fail(ctx, PT_ERR_INVALID, "pt_debug_render: null state");
+    if (width <= 0 || height <= 0 || width != ctx->scene.camera.res_x || height != ctx->scene.camera.res_y)
+        return Fail(ctx, PT_ERR_INVALID, "pt_debug_render: %dx%d does not match the camera's %dx%d", width, height, ctx->scene.camera.res_x,
+                    ctx->scene.camera.res_y);
+    if (state->debug_mode < PT_DEBUG_NONE || state->debug_mode > PT_DEBUG_ROUGHNESS) return Fail(ctx, PT_ERR_INVALID, "pt_debug_render: unknown debug_mode %d", state->debug_mode);
+    const bool bvh = state->visualize_bvh != 0 && state->debug_mode == PT_DEBUG_NONE;
+    if (bvh) {
+        if (state->bvh_visualize_type < PT_BVH_BOUNDS_HIT || state->bvh_visualize_type > PT_BVH_TRIANGLES_HIT)
+            return Fail(ctx, PT_ERR_INVALID, "pt_debug_render: unknown bvh_visualize_type %d", state->bvh_visualize_type);
+        if (state->bvh_visualize_type != PT_BVH_TRIANGLES_HIT && state->bvh_visualize_depth <= 0)
+            return Fail(ctx, PT_ERR_INVALID, "pt_debug_render: bvh_visualize_depth must be positive");
+    }
+    if (!bvh && state->debug_mode == PT_DEBUG_NONE) return PT_OK;  // the reference's Render writes nothing either
+    if (!image_device && !rgba_device) return PT_OK;
+    if (rgba_device && (reinterpret_cast<uintptr_t>(rgba_device) & 3u) != 0) return Fail(ctx, PT_ERR_INVALID, "rgba buffer must be 4-byte aligned");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, Join(ctx));  // lane 0's spill area is shared with render passes
+    HIP_TRY(ctx, hipMemsetAsync(ctx->cursor, 0, sizeof(uint32_t), ctx->stream));
+    const uint32_t tiles = (uint32_t(width + 7) >> 3) * (uint32_t(height + 7) >> 3);
+    const uint32_t n = tiles * 64u;
+    const uint32_t blocks = std::min<uint32_t>(ctx->grid_blocks, tiles);
+    const DebugParams p{state->visualize_bvh, state->bvh_visualize_type, state->bvh_visualize_depth, state->debug_mode, width, height};
+    hipLaunchKernelGGL(k_debug_view, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, p, image_device, rgba_device, n, ctx->cursor,
+                       ctx->lane[0].spill, ctx->spill_stride, ctx->dev_stats);
     HIP_TRY(ctx, hipGetLastError());
     return PT_OK;
 }

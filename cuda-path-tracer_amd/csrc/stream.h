@@ -38,6 +38,7 @@ struct Traversal {
     HitRec hit;
     bool found;      // MODE_ANY: an occluder was found
     TraceCounters ctr;
+    uint32_t tlas_interior;  // the TLAS's share of ctr.interior (counting variants only)
 
     // Returns false when the ray misses the scene's root box (kernel/intersection.h:162).
     PTD bool begin(const DScene &S, V3 origin, V3 dir, float tmax) {
@@ -49,7 +50,10 @@ struct Traversal {
         hit.rec = 0;
         hit.inst = -1;
         found = false;
-        if (COUNT) ctr = TraceCounters{0, 0, 0, 0};
+        if (COUNT) {
+            ctr = TraceCounters{0, 0, 0, 0};
+            tlas_interior = 0;
+        }
         iw = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         float t;
         if (!slab(o, iw, S.root_min[0], S.root_min[1], S.root_min[2], S.root_max[0], S.root_max[1], S.root_max[2], t_max, t)) return false;
@@ -96,7 +100,10 @@ struct Traversal {
     // One interior node: both child boxes, near child next, far child pushed
     // (kernel/intersection.h:114-135, :203-226).
     PTD void op_interior(const LaneStack &stk, LaneEvents &ev, float4 na, float4 nb, float4 nc, float4 nd) {
-        if (COUNT) ctr.interior++;
+        if (COUNT) {
+            ctr.interior++;
+            if (!in_blas) tlas_interior++;
+        }
         float tl, tr;
         const bool hl = slab(co, ci, na.x, na.y, na.z, nb.x, nb.y, nb.z, cbest, tl);
         const bool hr = slab(co, ci, nc.x, nc.y, nc.z, nd.x, nd.y, nd.z, cbest, tr);

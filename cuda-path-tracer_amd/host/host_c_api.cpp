@@ -224,6 +224,17 @@ int pth_integrator_render(pth_integrator *i, int w, int h, pth_scene *s, uint8_t
     if (!i || !s) return Fail("pth_integrator_render: null argument");
     return Guard([&] { i->impl.Render(w, h, s->scene, rgba_device, iteration, IntegratorState{}); });
 }
+int pth_debug_render(pt_ctx *ctx, int w, int h, pth_scene *s, const pt_integrator_state *state, uint8_t *rgba_device) {
+    if (!ctx || !s || !state) return Fail("pth_debug_render: null argument");
+    return Guard([&] {
+        IntegratorState st;
+        st.visualize_bvh = state->visualize_bvh != 0;
+        st.bvh_visualize_type = BVH_VisualizeMode(state->bvh_visualize_type);
+        st.bvh_visualize_depth = state->bvh_visualize_depth;
+        st.debug_mode = DebugVisualizeMode(state->debug_mode);
+        DebugIntegrator(ctx).Render(w, h, s->scene, rgba_device, 0, st);
+    });
+}
 
 // ------------------------------------------------------------ headless output
 static uint32_t Crc32(const uint8_t *data, size_t n, uint32_t crc) {

@@ -200,8 +200,17 @@ private:
     std::vector<pt_image> m_desc_images1, m_desc_images3;
 };
 
-struct IntegratorState {  // kernel/device_types.h:26-34 (debug views are out of scope)
+enum class DebugVisualizeMode { None, GeometricNormals, Albedo, UV, Depth, Metallic, Roughness };  // kernel/device_types.h:10-18
+enum class BVH_VisualizeMode { BoundsHit, TLAS, TrianglesHit };                                      // kernel/device_types.h:20-24
+
+struct IntegratorState {  // kernel/device_types.h:26-34
     bool dirty = false;
+
+    bool visualize_bvh = false;
+    BVH_VisualizeMode bvh_visualize_type = BVH_VisualizeMode::BoundsHit;
+    int bvh_visualize_depth = 500;
+
+    DebugVisualizeMode debug_mode = DebugVisualizeMode::None;
 };
 
 // kernel/integrators/integrator.h:11-24.
@@ -227,6 +236,23 @@ public:
     void Resize(int width, int height) override;
     void Reset(int width, int height) override;
     IntegratorType Type() override { return IntegratorType::Path; }
+    void Render(int width, int height, Scene &scene, uint8_t *data, int iteration,
+                const IntegratorState &state) override;
+
+private:
+    pt_ctx *m_ctx;
+};
+
+// kernel/integrators/debug.h:6-24.  The views are stateless on the device, so Init / Destroy /
+// Resize / Reset have nothing to allocate; `iteration` is unused, as in the reference.
+class DebugIntegrator : public Integrator {
+public:
+    explicit DebugIntegrator(pt_ctx *ctx) : m_ctx(ctx) {}
+    void Init(int, int) override {}
+    void Destroy() override {}
+    void Resize(int, int) override {}
+    void Reset(int, int) override {}
+    IntegratorType Type() override { return IntegratorType::Debug; }
     void Render(int width, int height, Scene &scene, uint8_t *data, int iteration,
                 const IntegratorState &state) override;
 

@@ -347,4 +347,16 @@ void PathIntegrator::Render(int w, int h, Scene &scene, uint8_t *data, int itera
     Check(m_ctx, pt_render(m_ctx, w, h, iteration, data), "pt_render");
 }
 
+// -------------------------------------------------------------- DebugIntegrator
+// kernel/integrators/debug.cu:198-239.
+void DebugIntegrator::Render(int w, int h, Scene &scene, uint8_t *data, int, const IntegratorState &state) {
+    scene.UpdateDevice(m_ctx);
+    pt_integrator_state st;
+    st.visualize_bvh = state.visualize_bvh ? 1 : 0;
+    st.bvh_visualize_type = int(state.bvh_visualize_type);
+    st.bvh_visualize_depth = state.bvh_visualize_depth;
+    st.debug_mode = int(state.debug_mode);
+    Check(m_ctx, pt_debug_render(m_ctx, w, h, &st, nullptr, data), "pt_debug_render");
+}
+
 }  // namespace pth

@@ -366,6 +366,10 @@ class Context:
     def tonemap(self, film_ptr: int, w, h, iterations, rgba_ptr: int):
         self._check(self._lib.pt_tonemap(self._h, C.c_void_p(film_ptr), w, h, iterations, C.c_void_p(rgba_ptr)))
 
+    def debug_render(self, w, h, state: abi.IntegratorState, image_ptr: int = 0, rgba_ptr: int = 0):
+        """DebugIntegrator::Render (debug.cu:198-239): BVH heat map or attribute view; asynchronous."""
+        self._check(self._lib.pt_debug_render(self._h, w, h, C.byref(state), C.c_void_p(image_ptr), C.c_void_p(rgba_ptr)))
+
     # batch queries on device pointers
     def trace_closest(self, rays_ptr: int, n: int, hits_ptr: int):
         self._check(self._lib.pt_trace_closest(self._h, C.c_void_p(rays_ptr), n, C.c_void_p(hits_ptr)))
@@ -439,3 +443,23 @@ class PathIntegrator:
 
     def render(self, w, h, scene: HostScene, rgba_device_ptr: int, iteration: int):
         _host_check(self._lib.pth_integrator_render(self._h, w, h, scene.handle, C.c_void_p(rgba_device_ptr), iteration))
+
+
+class DebugIntegrator:
+    """DebugIntegrator (kernel/integrators/debug.h:6-24) through the host facade: holds no device state."""
+
+    def __init__(self, ctx: Context):
+        self._lib = abi.load_library()
+        self._ctx = ctx
+
+    def init(self, w, h):
+        pass
+
+    def resize(self, w, h):
+        pass
+
+    def reset(self, w, h):
+        pass
+
+    def render(self, w, h, scene: HostScene, rgba_device_ptr: int, iteration: int, state: abi.IntegratorState):
+        _host_check(self._lib.pth_debug_render(self._ctx.handle, w, h, scene.handle, C.byref(state), C.c_void_p(rgba_device_ptr)))

@@ -308,8 +308,11 @@ int pt_render_async(pt_ctx *ctx, int width, int height, int iteration, uint8_t *
  * all their paths are in flight together, so every launch carries `samples` times the work
  * (path state grows to samples * W*H slots; MI355X's HBM is sized for that).  The film receives
  * the samples of a pixel in iteration order, so the result is bit-identical to `samples` calls
- * of pt_render.  Asynchronous like pt_render_async.  No counterpart in the reference, whose
- * Render traces one sample per call.                                                         */
+ * of pt_render.  Asynchronous like pt_render_async.  Consecutive passes run on two streams of
+ * the context's own, each starting after the work already submitted to the context's stream;
+ * every other entry point makes the context's stream wait for the passes in flight, and
+ * pt_synchronize waits for all of them.  No counterpart in the reference, whose Render traces
+ * one sample per call.                                                                       */
 int pt_render_batch(pt_ctx *ctx, int width, int height, int iteration, int samples, uint8_t *rgba_device);
 
 /* Film access (the reference keeps m_image private; the headless path and the
@@ -321,6 +324,39 @@ int pt_film_copy_from_device(pt_ctx *ctx, const float *rgb_device);
  * out = quantise(ACES(film / iterations)). film_device NULL = the ctx's film. */
 int pt_tonemap(pt_ctx *ctx, const float *film_device, int width, int height, int iterations,
                uint8_t *rgba_device);
+
+/* ------------------------------------------------------- debug integrator */
+
+/* DebugVisualizeMode / BVH_VisualizeMode / IntegratorState (kernel/device_types.h:10-34;
+ * the UI-only `dirty` flag is not part of the boundary).                       */
+enum {
+    PT_DEBUG_NONE = 0,
+    PT_DEBUG_GEOMETRIC_NORMALS = 1,
+    PT_DEBUG_ALBEDO = 2,
+    PT_DEBUG_UV = 3,
+    PT_DEBUG_DEPTH = 4,
+    PT_DEBUG_METALLIC = 5,
+    PT_DEBUG_ROUGHNESS = 6
+};
+enum { PT_BVH_BOUNDS_HIT = 0, PT_BVH_TLAS = 1, PT_BVH_TRIANGLES_HIT = 2 };
+typedef struct pt_integrator_state {
+    int32_t visualize_bvh;       /* bool */
+    int32_t bvh_visualize_type;  /* PT_BVH_* */
+    int32_t bvh_visualize_depth; /* heat-map scale, 500 in the reference */
+    int32_t debug_mode;          /* PT_DEBUG_* */
+} pt_integrator_state;
+
+/* Replaces DebugIntegrator::Render (kernel/integrators/debug.cu:198-239): one pixel-centre
+ * camera ray per pixel; the BVH heat map (VisualizeBVH, :119-178: nodes visited / TLAS nodes
+ * visited / triangles tested) when visualize_bvh is set, replaced by the attribute view
+ * (DebugView, :51-117: normals, albedo, uv, depth, metallic, roughness) when debug_mode is not
+ * PT_DEBUG_NONE; with neither, nothing is written, as in the reference.  image_device =
+ * W*H*3 fp32 (the reference's private m_image), rgba_device = W*H uchar4 after
+ * SendImageToBuffer (:180-196); both are DEVICE pointers and either may be NULL.  width and
+ * height must equal the camera's resolution.  Needs no pt_integrator_init.  Asynchronous on
+ * the context's stream.                                                        */
+int pt_debug_render(pt_ctx *ctx, int width, int height, const pt_integrator_state *state,
+                    float *image_device, uint8_t *rgba_device);
 
 /* ------------------------------------------------- batch ray queries (metric) */
 

@@ -77,6 +77,10 @@ int pth_integrator_resize(pth_integrator *integrator, int width, int height);
 int pth_integrator_reset(pth_integrator *integrator, int width, int height);
 int pth_integrator_render(pth_integrator *integrator, int width, int height, pth_scene *scene, uint8_t *rgba_device,
                           int iteration);
+/* ---- DebugIntegrator::Render (kernel/integrators/debug.h:6-24, debug.cu:198-239): scene
+ * update, then pt_debug_render into rgba_device.                              */
+int pth_debug_render(pt_ctx *ctx, int width, int height, pth_scene *scene, const pt_integrator_state *state,
+                     uint8_t *rgba_device);
 
 /* ---- headless output replacing the display path (application.cpp:157-179, image.cpp:105-139):
  * writes an 8-bit RGB PNG (stored-deflate) or a Radiance .hdr of a fp32 film / iterations. */

@@ -181,6 +181,7 @@ struct Counters {
     uint64_t tlas_leaves = 0;  // TLAS leaves entered
     uint64_t tris = 0;         // triangles tested
     uint64_t blas_leaves = 0;  // BLAS leaves visited
+    uint64_t tlas_interior = 0;  // the TLAS's share of `interior`
     uint32_t drops = 0;        // pushes dropped at depth 64
     uint32_t max_depth = 0;    // deepest stack seen (either level)
 };
@@ -323,7 +324,7 @@ static bool IntersectScene(const Scene &scene, const Ray &ray, Intersection &int
                 break;
             }
         } else {
-            if (ctr) ctr->interior++;
+            if (ctr) { ctr->interior++; ctr->tlas_interior++; }
             uint32_t left = node.left_right & 0xFFFFu;
             uint32_t right = node.left_right >> 16;
             float left_time, right_time;
@@ -1460,6 +1461,102 @@ static void parallel_for(size_t n, int nthreads, F f) {
 
 // =================================================================== C API
 using namespace ora;
+// ---- DebugIntegrator (kernel/integrators/debug.cu:42-239) ----
+// math/color.h:19-48
+static vec3 WavelengthToXYZ(float wavelength) {
+    vec3 result;
+    {
+        float t1 = (wavelength - 442.0f) * ((wavelength < 442.0f) ? 0.0624f : 0.0374f);
+        float t2 = (wavelength - 599.8f) * ((wavelength < 599.8f) ? 0.0264f : 0.0323f);
+        float t3 = (wavelength - 501.1f) * ((wavelength < 501.1f) ? 0.0490f : 0.0382f);
+        result.x = 0.362f * expf(-0.5f * t1 * t1) + 1.056f * expf(-0.5f * t2 * t2) - 0.065f * expf(-0.5f * t3 * t3);
+    }
+    {
+        float t1 = (wavelength - 568.8f) * ((wavelength < 568.8f) ? 0.0213f : 0.0247f);
+        float t2 = (wavelength - 530.9f) * ((wavelength < 530.9f) ? 0.0613f : 0.0322f);
+        result.y = 0.821f * expf(-0.5f * t1 * t1) + 0.286f * expf(-0.5f * t2 * t2);
+    }
+    {
+        float t1 = (wavelength - 437.0f) * ((wavelength < 437.0f) ? 0.0845f : 0.0278f);
+        float t2 = (wavelength - 459.0f) * ((wavelength < 459.0f) ? 0.0385f : 0.0725f);
+        result.z = 1.217f * expf(-0.5f * t1 * t1) + 0.681f * expf(-0.5f * t2 * t2);
+    }
+    return result;
+}
+// math/color.h:50-56
+static vec3 XYZ_To_LinearRGB(vec3 xyz) {
+    return {3.240479f * xyz.x - 1.537150f * xyz.y - 0.498535f * xyz.z,
+            -0.969256f * xyz.x + 1.875991f * xyz.y + 0.041556f * xyz.z,
+            0.055648f * xyz.x - 0.204043f * xyz.y + 1.057311f * xyz.z};
+}
+static inline float glm_clamp(float x, float lo, float hi) {  // glm::clamp = min(max(x, lo), hi)
+    float m = (x < lo) ? lo : x;
+    return (hi < m) ? hi : m;
+}
+// math/color.h:73-79
+static float Gamma_sRGB(float c) {
+    c = glm_clamp(c, 0.0f, 1.0f);
+    if (c <= 0.0031308f) return 12.92f * c;
+    return 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
+}
+// debug.cu:42-49
+static vec3 HeatMapColor(int depth, int max_depth) {
+    float t = static_cast<float>(depth) / max_depth;
+    float lambda = 380.0f * (1.0f - t) + 780.0f * t;  // glm::mix(VISIBLE_SPECTRUM_BEGIN, VISIBLE_SPECTRUM_END, t)
+    vec3 rgb = XYZ_To_LinearRGB(WavelengthToXYZ(lambda));
+    return {Gamma_sRGB(rgb.x), Gamma_sRGB(rgb.y), Gamma_sRGB(rgb.z)};
+}
+// VisualizeBVH<Mode>, debug.cu:119-178.  The traversal callback runs once per node that
+// survives the pop-time cull (kernel/intersection.h:61,181): every expanded interior node and
+// every entered leaf of either level.
+static vec3 VisualizeBVH(const Scene &scene, const Ray &ray, int mode, int bvh_visualize_depth) {
+    Counters c;
+    Intersection is;
+    IntersectScene<CLOSEST>(scene, ray, is, FLT_MAX, &c);
+    if (mode == PT_BVH_BOUNDS_HIT) {
+        int depth = int(c.interior + c.tlas_leaves + c.blas_leaves);
+        return HeatMapColor(depth, bvh_visualize_depth);
+    }
+    if (mode == PT_BVH_TLAS) {
+        int depth = int(c.tlas_interior + c.tlas_leaves);
+        return HeatMapColor(depth, bvh_visualize_depth);
+    }
+    int tri_count = int(c.tris);  // CLOSEST tests every triangle of a visited leaf: sum of primitive_count
+    const float MAX_TRIS = 50.0f;
+    float t = logf(tri_count + 1.0f) / logf(MAX_TRIS + 1.0f);
+    t = glm_clamp(t, 0.0f, 1.0f);
+    vec3 green{0.0f, 0.3f, 0.0f}, yellow{1.0f, 1.0f, 0.0f};
+    return green * (1.0f - t) + yellow * t;
+}
+// DebugView<Mode>, debug.cu:51-117.
+static vec3 DebugView(const Scene &scene, const Ray &ray, int mode) {
+    const pt_scene_desc &d = *scene.d;
+    const vec3 background = V3(0.4f);
+    Intersection is;
+    if (!IntersectScene<CLOSEST>(scene, ray, is, FLT_MAX, nullptr)) return background;
+    const pt_material &material = d.materials[is.material_id];
+    switch (mode) {
+    case PT_DEBUG_GEOMETRIC_NORMALS: return is.normal;
+    case PT_DEBUG_ALBEDO:
+        if (material.type == PT_MAT_LAMBERTIAN || material.type == PT_MAT_METALLIC_ROUGHNESS) return SampleTexture3(d, material.tex0, is.uv);
+        return V3(0.0f);
+    case PT_DEBUG_METALLIC:
+        if (material.type == PT_MAT_METALLIC_ROUGHNESS) return V3(SampleTexture1(d, material.w1.i, is.uv));
+        return V3(0.0f);
+    case PT_DEBUG_ROUGHNESS:
+        if (material.type == PT_MAT_METALLIC_ROUGHNESS) return V3(SampleTexture1(d, material.w2, is.uv));
+        return V3(0.0f);
+    case PT_DEBUG_UV: return vec3{is.uv.x, is.uv.y, 0.0f};
+    case PT_DEBUG_DEPTH: {
+        float near_clip = d.camera.near_plane, far_clip = d.camera.far_plane, t = is.time;
+        if (t < near_clip || t > far_clip) return background;
+        float depth = (t - near_clip) / (far_clip - near_clip);
+        return V3(glm_clamp(depth, 0.0f, 1.0f));
+    }
+    }
+    return V3(0.0f);
+}
+
 extern "C" {
 
 int ora_intersect_aabb(const float *o, const float *dir, const float *bmin, const float *bmax, float t_max, float *t_out) {
@@ -1709,6 +1806,34 @@ void ora_tonemap(const float *film, int width, int height, int iteration, uint8_
         }
         rgba[i * 4 + 3] = 255;
     }
+}
+// DebugIntegrator::Render (debug.cu:198-239) for one frame: the BVH view when visualize_bvh is
+// set, replaced by the debug view when debug_mode is not None; neither = nothing written.
+// image = W*H*3 fp32 (the reference's m_image) and rgba = W*H*4 (SendImageToBuffer, :180-196);
+// either may be null.
+int ora_debug_render(const pt_scene_desc *desc, int width, int height, const pt_integrator_state *state, float *image,
+                     uint8_t *rgba, int nthreads) {
+    const bool view = state->debug_mode != PT_DEBUG_NONE;
+    if (!view && !state->visualize_bvh) return 0;
+    Scene scene = make_scene(desc);
+    parallel_for(size_t(width) * height, nthreads, [&](size_t b, size_t e, int) {
+        for (size_t idx = b; idx < e; ++idx) {
+            int x = int(idx % width), y = int(idx / width);
+            Ray ray = SpawnCameraRay(desc->camera, x, y, 0.5f, 0.5f);
+            vec3 c = view ? DebugView(scene, ray, state->debug_mode)
+                          : VisualizeBVH(scene, ray, state->bvh_visualize_type, state->bvh_visualize_depth);
+            if (image) { image[idx * 3 + 0] = c.x; image[idx * 3 + 1] = c.y; image[idx * 3 + 2] = c.z; }
+            if (rgba) {
+                const float p[3] = {c.x, c.y, c.z};
+                for (int k = 0; k < 3; ++k) {
+                    int v = (int)(p[k] * 255.0);
+                    rgba[idx * 4 + k] = uint8_t(std::min(std::max(v, 0), 255));
+                }
+                rgba[idx * 4 + 3] = 255;
+            }
+        }
+    });
+    return 0;
 }
 // Direct access to the pieces the shading tests compare one by one.
 void ora_sample_texture3(const pt_scene_desc *desc, int texture_id, float u, float v, float *rgb) {

@@ -63,6 +63,7 @@ def lib() -> C.CDLL:
         "ora_render": (i32, [dp, i32, i32, i32, vp, C.POINTER(u64), i32]),
         "ora_capture_bounce_rays": (sz, [dp, i32, i32, i32, i32, vp, sz]),
         "ora_tonemap": (None, [vp, i32, i32, i32, vp]),
+        "ora_debug_render": (i32, [dp, i32, i32, C.POINTER(abi.IntegratorState), vp, vp, i32]),
         "ora_sample_texture3": (None, [dp, i32, f32, f32, fp]),
         "ora_sample_texture1": (f32, [dp, i32, f32, f32]),
         "ora_pcg_stream": (None, [i32, i32, i32, i32, fp]),
@@ -203,6 +204,14 @@ def tonemap(film, iteration):
     out = np.zeros((h, w, 4), np.uint8)
     lib().ora_tonemap(abi.vptr(np.ascontiguousarray(film, np.float32)), w, h, iteration, abi.vptr(out))
     return out
+
+
+def debug_render(desc, w, h, state, nthreads=1):
+    """DebugIntegrator::Render: (float image HxWx3, rgba HxWx4); both untouched (zeros) when no view is selected."""
+    image = np.zeros((h, w, 3), np.float32)
+    rgba = np.zeros((h, w, 4), np.uint8)
+    lib().ora_debug_render(C.byref(desc), w, h, C.byref(state), abi.vptr(image), abi.vptr(rgba), nthreads)
+    return image, rgba
 
 
 def pcg_stream(px, py, iteration, n):

@@ -107,3 +107,32 @@ def test_gpu_reproduces_golden_render(pt, gpu_ctx, tiny_scene, devbuf):
     assert close.mean() >= 0.97
     img = rgba.download(np.uint8, 64 * 48 * 4).reshape(48, 64, 4)
     assert (np.abs(img.astype(int) - g["rgba_iter1"].astype(int)) <= 1).mean() >= 0.95
+
+
+DEBUG_CASES = ([("bvh_" + n, (1, k, 60, 0)) for k, n in enumerate(("bounds_hit", "tlas", "triangles_hit"))] +
+               [("view_" + n, (0, 0, 500, k)) for k, n in enumerate(("normals", "albedo", "uv", "depth", "metallic", "roughness"), start=1)])
+
+
+def test_oracle_reproduces_golden_debug_views(pt, ora, tiny_scene):
+    g = np.load(os.path.join(GOLDEN, "debug_tiny.npz"))
+    assert sorted(g.files) == sorted(k for k, _ in DEBUG_CASES)
+    for key, state in DEBUG_CASES:
+        _, rgba = ora.debug_render(tiny_scene.desc(), 64, 48, pt.abi.IntegratorState(*state), nthreads=4)
+        assert np.array_equal(rgba, g[key]), key
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_golden_debug_views(pt, gpu_ctx, tiny_scene, devbuf):
+    """Attribute views bit-exact; heat maps within one 8-bit level (expf / powf differ by ulps)."""
+    g = np.load(os.path.join(GOLDEN, "debug_tiny.npz"))
+    gpu_ctx.upload(tiny_scene.desc())
+    rgba = devbuf(64 * 48 * 4)
+    for key, state in DEBUG_CASES:
+        gpu_ctx.debug_render(64, 48, pt.abi.IntegratorState(*state), 0, rgba.ptr)
+        gpu_ctx.synchronize()
+        img = rgba.download(np.uint8, 64 * 48 * 4).reshape(48, 64, 4)
+        if key.startswith("view_"):
+            assert np.array_equal(img, g[key]), key
+        else:
+            diff = np.abs(img.astype(int) - g[key].astype(int))
+            assert diff.max() <= 1 and (diff > 0).mean() < 0.01, key

@@ -249,3 +249,78 @@ def test_render_is_deterministic_and_thread_independent(ora, tiny_scene):
     b, sb = ora.render(d, 64, 48, 2, nthreads=4)
     assert np.array_equal(a, b) and sa == sb
     assert np.isfinite(a).all() and a.mean() > 0.01
+
+
+# ------------------------------------------------------------------ debug integrator
+def _debug_state(pt, visualize_bvh=0, bvh_type=0, depth=500, mode=0):
+    return pt.abi.IntegratorState(visualize_bvh, bvh_type, depth, mode)
+
+
+def test_debug_heat_map_follows_the_visit_counters(pt, ora, tiny_scene):
+    """BoundsHit / TLAS / TrianglesHit colours are functions of the traversal counters of the
+    pixel-centre camera ray (debug.cu:119-178), recomputed here in float64."""
+    w, h = 64, 48
+    desc = tiny_scene.desc()
+    rays = np.zeros(w * h, pt.abi.RAY)
+    o, d = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    for y in range(h):
+        for x in range(w):
+            ora.lib().ora_camera_ray(desc.camera, x, y, 0.5, 0.5, pt.abi.fptr(o), pt.abi.fptr(d))
+            rays[y * w + x]["origin"], rays[y * w + x]["direction"], rays[y * w + x]["tmax"] = o, d, np.float32(3.4028235e38)
+    tris = np.zeros(w * h, np.int64)
+    visits = np.zeros(w * h, np.int64)
+    for i in range(w * h):
+        _, c = ora.trace_closest(desc, rays[i:i + 1], counters=True)
+        tris[i] = c[2]
+        visits[i] = c[0] + c[1] + c[3]
+    image, rgba = ora.debug_render(desc, w, h, _debug_state(pt, 1, pt.abi.PT_BVH_TRIANGLES_HIT))
+    t = np.clip(np.log(tris + 1.0) / np.log(51.0), 0, 1).reshape(h, w)
+    assert np.abs(image[..., 0] - t).max() < 1e-5
+    assert np.abs(image[..., 1] - (0.3 * (1 - t) + t)).max() < 1e-5
+    assert not image[..., 2].any() and (rgba[..., 3] == 255).all()
+
+    def heat(depth, scale):  # HeatMapColor, debug.cu:42-49 + math/color.h:19-87
+        lam = 380.0 + 400.0 * depth / scale
+
+        def g(mu, s1, s2):
+            return np.exp(-0.5 * ((lam - mu) * np.where(lam < mu, s1, s2)) ** 2)
+        X = 0.362 * g(442.0, 0.0624, 0.0374) + 1.056 * g(599.8, 0.0264, 0.0323) - 0.065 * g(501.1, 0.0490, 0.0382)
+        Y = 0.821 * g(568.8, 0.0213, 0.0247) + 0.286 * g(530.9, 0.0613, 0.0322)
+        Z = 1.217 * g(437.0, 0.0845, 0.0278) + 0.681 * g(459.0, 0.0385, 0.0725)
+        rgb = np.stack([3.240479 * X - 1.537150 * Y - 0.498535 * Z, -0.969256 * X + 1.875991 * Y + 0.041556 * Z,
+                        0.055648 * X - 0.204043 * Y + 1.057311 * Z], -1).clip(0, 1)
+        return np.where(rgb <= 0.0031308, 12.92 * rgb, 1.055 * rgb ** (1 / 2.4) - 0.055)
+
+    image, rgba = ora.debug_render(desc, w, h, _debug_state(pt, 1, pt.abi.PT_BVH_BOUNDS_HIT, 60))
+    ref = heat(visits.reshape(h, w).astype(np.float64), 60.0)
+    assert np.abs(image - ref).max() < 2e-4
+    assert visits.max() > visits.min() and image.std() > 1e-2
+    # 8-bit conversion: truncation of p * 255 (debug.cu:190-192)
+    assert np.abs(rgba[..., :3].astype(int) - np.floor(ref * 255.0).clip(0, 255).astype(int)).max() <= 1
+    # TLAS nodes visited never exceed all nodes visited
+    tl, _ = ora.debug_render(desc, w, h, _debug_state(pt, 1, pt.abi.PT_BVH_TLAS, 60))
+    assert tl.shape == image.shape and np.isfinite(tl).all()
+
+
+def test_debug_attribute_views(pt, ora, tiny_scene):
+    """DebugView (debug.cu:51-117): background 0.4 off the scene; normals are unit vectors; depth is
+    the clamped normalised hit distance; albedo is zero on materials without an albedo view."""
+    w, h = 64, 48
+    desc = tiny_scene.desc()
+    normals, _ = ora.debug_render(desc, w, h, _debug_state(pt, mode=pt.abi.PT_DEBUG_GEOMETRIC_NORMALS))
+    depth, _ = ora.debug_render(desc, w, h, _debug_state(pt, mode=pt.abi.PT_DEBUG_DEPTH))
+    uv, _ = ora.debug_render(desc, w, h, _debug_state(pt, mode=pt.abi.PT_DEBUG_UV))
+    albedo, rgba = ora.debug_render(desc, w, h, _debug_state(pt, mode=pt.abi.PT_DEBUG_ALBEDO))
+    bg = np.all(normals == np.float32(0.4), axis=2)
+    assert 0 < bg.sum() < w * h
+    assert np.allclose(np.linalg.norm(normals[~bg], axis=1), 1.0, atol=1e-5)
+    assert np.all(depth[bg] == np.float32(0.4)) and np.all(uv[bg] == np.float32(0.4))
+    assert (depth[~bg] >= 0).all() and (depth[~bg] <= 1).all() and not uv[~bg][:, 2].any()
+    assert np.all(depth[..., 0] == depth[..., 1])
+    # the checkerboard floor shows exactly its two colours somewhere; mirror / dielectric / emissive give 0
+    flat = albedo[~bg].reshape(-1, 3)
+    colours = {tuple(round(float(x), 4) for x in c) for c in np.unique(flat, axis=0)}
+    assert (0.8, 0.8, 0.8) in colours and (0.2, 0.3, 0.8) in colours and (0.0, 0.0, 0.0) in colours
+    assert (rgba[..., :3][bg] == 102).all()  # (int)(0.4f * 255.0) = 102
+    none_img, none_rgba = ora.debug_render(desc, w, h, _debug_state(pt))
+    assert not none_img.any() and not none_rgba.any()

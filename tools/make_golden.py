@@ -57,6 +57,14 @@ def main():
                         rgba_iter1=ora.tonemap(film2, iteration=1))
     print("render tiny mean", float(film.mean()), counts)
 
+    # debug integrator: every BVH map (scale 60) and every attribute view of the tiny scene, 8-bit
+    debug = {}
+    for k, name in enumerate(("bounds_hit", "tlas", "triangles_hit")):
+        debug["bvh_" + name] = ora.debug_render(tiny.desc(), 64, 48, pt.abi.IntegratorState(1, k, 60, 0), nthreads=4)[1]
+    for k, name in enumerate(("normals", "albedo", "uv", "depth", "metallic", "roughness"), start=1):
+        debug["view_" + name] = ora.debug_render(tiny.desc(), 64, 48, pt.abi.IntegratorState(0, 0, 500, k), nthreads=4)[1]
+    np.savez_compressed(os.path.join(OUT, "debug_tiny.npz"), **debug)
+
     streams = np.stack([ora.pcg_stream(px, py, it, 16) for px, py, it in ((0, 0, 0), (5, 7, 0), (1919, 1079, 3), (65535, 65535, 1000))])
     weights = np.array([0.5, 3.0, 1.0, 0.0, 2.5, 1.0, 1.0, 7.0], np.float32)
     _, prob, alias = ora.alias_build(weights)
