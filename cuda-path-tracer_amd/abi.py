@@ -137,7 +137,7 @@ PT_SYMBOLS = [
     "pt_render_async", "pt_render_batch", "pt_film_download", "pt_film_copy_to_device", "pt_film_copy_from_device", "pt_tonemap",
     "pt_trace_closest", "pt_trace_any", "pt_resolve_hits", "pt_trace_closest_counted", "pt_trace_closest_host",
     "pt_trace_any_host", "pt_resolve_hits_host", "pt_generate_incoherent_rays", "pt_capture_bounce_rays",
-    "pt_set_trace_mode", "pt_debug_render"]
+    "pt_set_trace_mode", "pt_debug_render", "pt_bvh_build", "pt_bvh_sizes", "pt_bvh_get", "pt_bvh_timing", "pt_bvh_free"]
 PTH_SYMBOLS = [
     "pth_last_error", "pth_transform_matrix", "pth_matrix_derive", "pth_matrix_mul", "pth_gltf_local_matrix",
     "pth_alias_build", "pth_camera_make", "pth_bvh_build", "pth_bvh_sizes", "pth_bvh_get", "pth_bvh_free",
@@ -206,6 +206,11 @@ def load_library() -> C.CDLL:
         "pt_generate_incoherent_rays": (i32, [vp, vp, sz, u64]),
         "pt_capture_bounce_rays": (i32, [vp, i32, i32, i32, i32, vp, sz, C.POINTER(sz)]),
         "pt_set_trace_mode": (i32, [vp, i32]),
+        "pt_bvh_build": (i32, [vp, fp, u32, up, u32, vp, u32, C.POINTER(vp)]),
+        "pt_bvh_sizes": (i32, [vp, up, up, up, up]),
+        "pt_bvh_get": (i32, [vp, vp, vp, vp, vp]),
+        "pt_bvh_timing": (i32, [vp, fp, fp, up]),
+        "pt_bvh_free": (None, [vp]),
         "pt_debug_render": (i32, [vp, i32, i32, C.POINTER(IntegratorState), vp, vp]),
         "pth_last_error": (C.c_char_p, []),
         "pth_transform_matrix": (i32, [fp, fp, fp, fp]),

@@ -1,0 +1,890 @@
+// Acceleration-structure build on the device: every BLAS (binned SAH, 8 bins) and the TLAS
+// (agglomerative pairing) of a scene, producing the arrays of the reference's builder
+// (bvh.cpp:5-332) bit for bit: same tree, same node numbering, same triangle permutation.
+//
+// The reference builds one node at a time, depth first.  Here all nodes of one depth, over all
+// meshes at once, are processed per pass, with one thread per triangle position:
+//   * bounds and bins are reductions; min / max do not depend on the order of their operands
+//     except for the sign of a zero, so node boxes are reduced as (value, position) keys and
+//     read back from the winning triangle: the box holds the value the reference's sequential
+//     union would have kept (the first one met among equals);
+//   * the plane sweep of a node (21 candidates, first strictly smaller cost wins) is sequential
+//     code run by one thread per node;
+//   * the reference partitions a node's triangle list in place with two cursors
+//     (bvh.cpp:80-86), which is not a stable partition.  Where each entry ends up has a closed
+//     form in terms of ranks (see PartitionDest), so the same permutation is produced by a scan
+//     and a scatter;
+//   * nodes are numbered breadth first while building and renumbered at the end: the reference
+//     allocates a node's two children when it subdivides the node, in depth-first order, so
+//     the left child of the k-th subdivided node (preorder) is node 1 + 2k.
+// The TLAS pairing loop (bvh.cpp:283-331) is a chain of arg-min searches, each depending on
+// the previous merge; one workgroup runs the chain with every search spread over its lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/ptamd.h"
+
+namespace ptb {
+
+constexpr int kBins = 8;
+constexpr uint32_t kScanBlock = 256, kScanItems = 8, kScanTile = kScanBlock * kScanItems;
+constexpr uint32_t kMaxPrims = kScanTile * 8192u;  // one level of block sums is scanned by a single block
+
+#define PTB_D __device__ __forceinline__
+
+PTB_D float fmin_ref(float a, float b) { return b < a ? b : a; }  // glm::min
+PTB_D float fmax_ref(float a, float b) { return a < b ? b : a; }  // glm::max
+
+// Monotone float -> unsigned map (negative values reversed below the positive ones).
+PTB_D uint32_t enc(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+PTB_D float dec(uint32_t e) { return __uint_as_float((e & 0x80000000u) ? (e & 0x7FFFFFFFu) : ~e); }
+// Same, with both zeros on one key: equal values then compete on the position alone.
+PTB_D uint32_t enc_eq(float f) { return enc(f == 0.0f ? 0.0f : f); }
+
+struct BNode {  // build-time node, breadth-first numbering; roots are nodes 0..blas_count-1
+    uint32_t first, count;  // positions [first, first + count) of the order array
+    uint32_t left;          // breadth-first index of the left child (right = left + 1); 0 = leaf
+    uint32_t blas;
+    float lo[3], hi[3];
+    uint32_t cb_lo[3], cb_hi[3];  // centroid bounds of this pass, enc()
+    int32_t axis;                 // split axis of this pass, -1 = none
+    uint32_t bin_slot;            // this pass's Bins record (only nodes that may split own one)
+    float pos;
+    uint32_t n_right;             // entries not left of the plane
+    uint32_t pairs, front_rights; // K and K' of PartitionDest
+    uint32_t internal;            // subdivided nodes in the subtree (itself included)
+    uint32_t rank;                // preorder rank among its mesh's subdivided nodes
+    uint32_t index;               // final index inside its mesh's node array
+};
+
+struct Bins {  // 8 bins on each axis: enc()-coded boxes and counts
+    uint32_t lo[3][kBins][3], hi[3][kBins][3];
+    uint32_t count[3][kBins];
+};
+
+struct Prims {  // per triangle, mesh-major order (the mesh's triangles keep their own order)
+    float *lo[3], *hi[3], *centroid[3];
+    uint32_t *blas;  // mesh of the triangle
+};
+
+struct MeshInfo {
+    uint32_t first_index;  // into the scene's index array
+    uint32_t tri_first;    // first triangle position of the mesh
+    uint32_t tri_count;
+    uint32_t node_offset;  // first node of the mesh in the flattened node array (set at the end)
+};
+
+// ------------------------------------------------------------------ setup
+__global__ void kb_prims(const float *positions, const uint32_t *indices, const MeshInfo *meshes, uint32_t mesh_count, Prims P, uint32_t n,
+                         uint32_t *order, uint32_t *node_of) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    uint32_t lo = 0, hi = mesh_count;  // last mesh with tri_first <= g among the non-empty ones
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (meshes[mid].tri_first <= g) lo = mid; else hi = mid;
+    }
+    while (meshes[lo].tri_count == 0 || g - meshes[lo].tri_first >= meshes[lo].tri_count) --lo;  // empty meshes share a tri_first
+    const MeshInfo m = meshes[lo];
+    const uint32_t t = g - m.tri_first;
+    const float *v[3];
+    for (int k = 0; k < 3; ++k) v[k] = positions + 3 * size_t(indices[m.first_index + 3 * t + k]);
+    for (int a = 0; a < 3; ++a) {  // AddPoint x3 (bvh.cpp:38-41), centroid (bvh.cpp:36)
+        float mn = fmin_ref(FLT_MAX, v[0][a]), mx = fmax_ref(-FLT_MAX, v[0][a]);
+        mn = fmin_ref(mn, v[1][a]);
+        mx = fmax_ref(mx, v[1][a]);
+        mn = fmin_ref(mn, v[2][a]);
+        mx = fmax_ref(mx, v[2][a]);
+        P.lo[a][g] = mn;
+        P.hi[a][g] = mx;
+        P.centroid[a][g] = ((v[0][a] + v[1][a]) + v[2][a]) * (1.0f / 3.0f);
+    }
+    P.blas[g] = lo;
+    order[g] = g;
+    node_of[g] = lo;
+}
+
+__global__ void kb_roots(BNode *nodes, const MeshInfo *meshes, uint32_t mesh_count, unsigned long long *keys) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= mesh_count) return;
+    BNode n = {};
+    n.first = meshes[b].tri_first;
+    n.count = meshes[b].tri_count;
+    n.blas = b;
+    n.axis = -1;
+    nodes[b] = n;
+    for (int k = 0; k < 3; ++k) {
+        keys[6 * size_t(b) + k] = ~0ull;
+        keys[6 * size_t(b) + 3 + k] = 0ull;
+    }
+}
+
+// Box of the nodes [begin, end): union of the boxes of their entries, as (value, position) keys.
+__global__ void kb_bounds_keys(const BNode *nodes, uint32_t begin, uint32_t end, const uint32_t *node_of, const uint32_t *order, Prims P, uint32_t n,
+                               unsigned long long *keys) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = node_of[i];
+    if (v < begin || v >= end) return;
+    const uint32_t prim = order[i];
+    for (int a = 0; a < 3; ++a) {
+        atomicMin(&keys[6 * size_t(v) + a], ((unsigned long long)enc_eq(P.lo[a][prim]) << 32) | i);
+        atomicMax(&keys[6 * size_t(v) + 3 + a], ((unsigned long long)enc_eq(P.hi[a][prim]) << 32) | (0xFFFFFFFFu - i));
+    }
+}
+__global__ void kb_bounds_decode(BNode *nodes, uint32_t begin, uint32_t end, const unsigned long long *keys, const uint32_t *order, Prims P) {
+    const uint32_t v = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= end) return;
+    BNode &n = nodes[v];
+    if (n.count == 0) return;
+    for (int a = 0; a < 3; ++a) {
+        n.lo[a] = P.lo[a][order[uint32_t(keys[6 * size_t(v) + a])]];
+        n.hi[a] = P.hi[a][order[0xFFFFFFFFu - uint32_t(keys[6 * size_t(v) + 3 + a])]];
+    }
+}
+
+// ------------------------------------------------------------------ one pass over a level
+PTB_D bool node_active(const BNode &n) { return n.count > 2; }  // bvh.cpp:69
+
+__global__ void kb_level_init(BNode *nodes, uint32_t begin, uint32_t end, Bins *bins, uint32_t *slot_counter) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (begin + k >= end) return;
+    BNode &n = nodes[begin + k];
+    n.axis = -1;
+    if (!node_active(n)) return;
+    for (int a = 0; a < 3; ++a) {
+        n.cb_lo[a] = 0xFFFFFFFFu;
+        n.cb_hi[a] = 0u;
+    }
+    n.bin_slot = atomicAdd(slot_counter, 1u);  // at most (triangles / 3) nodes of a level hold 3 or more
+    Bins &b = bins[n.bin_slot];
+    for (int a = 0; a < 3; ++a)
+        for (int j = 0; j < kBins; ++j) {
+            b.count[a][j] = 0;
+            for (int c = 0; c < 3; ++c) {
+                b.lo[a][j][c] = 0xFFFFFFFFu;
+                b.hi[a][j][c] = 0u;
+            }
+        }
+}
+
+__global__ void kb_centroid_bounds(BNode *nodes, uint32_t begin, uint32_t end, const uint32_t *node_of, const uint32_t *order, Prims P, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = node_of[i];
+    if (v < begin || v >= end || !node_active(nodes[v])) return;
+    const uint32_t prim = order[i];
+    for (int a = 0; a < 3; ++a) {
+        const uint32_t e = enc(P.centroid[a][prim]);
+        atomicMin(&nodes[v].cb_lo[a], e);
+        atomicMax(&nodes[v].cb_hi[a], e);
+    }
+}
+
+// bvh.cpp:151-165: bin index of a centroid on every axis whose centroid extent is positive.
+__global__ void kb_bin(const BNode *nodes, uint32_t begin, uint32_t end, const uint32_t *node_of, const uint32_t *order, Prims P, uint32_t n, Bins *bins) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = node_of[i];
+    if (v < begin || v >= end || !node_active(nodes[v])) return;
+    const BNode &nd = nodes[v];
+    const uint32_t prim = order[i];
+    Bins &b = bins[nd.bin_slot];
+    for (int a = 0; a < 3; ++a) {
+        const float cmin = dec(nd.cb_lo[a]), cmax = dec(nd.cb_hi[a]);
+        const float extent = cmax - cmin;
+        if (extent <= 0.0f) continue;
+        const float inv_width = 1.0f / fmax_ref(extent, 1e-30f);
+        const float scaled = (P.centroid[a][prim] - cmin) * inv_width;
+        int j = int(scaled * kBins);
+        j = j < 0 ? 0 : (j > kBins - 1 ? kBins - 1 : j);
+        atomicAdd(&b.count[a][j], 1u);
+        for (int c = 0; c < 3; ++c) {
+            atomicMin(&b.lo[a][j][c], enc(P.lo[c][prim]));
+            atomicMax(&b.hi[a][j][c], enc(P.hi[c][prim]));
+        }
+    }
+}
+
+struct RBox {
+    float lo[3], hi[3];
+    PTB_D void reset() {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = FLT_MAX;
+            hi[a] = -FLT_MAX;
+        }
+    }
+    PTB_D void grow(const float *l, const float *h) {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fmin_ref(lo[a], l[a]);
+            hi[a] = fmax_ref(hi[a], h[a]);
+        }
+    }
+    PTB_D float area() const {  // SurfaceArea, math/aabb.h
+        const float dx = fmax_ref(hi[0] - lo[0], 0.0f), dy = fmax_ref(hi[1] - lo[1], 0.0f), dz = fmax_ref(hi[2] - lo[2], 0.0f);
+        return 2.0f * (dx * dy + dy * dz + dz * dx);
+    }
+};
+
+// FindSplitPlane's sweep and Subdivide's cost test (bvh.cpp:72-77,167-198), one thread per node.
+__global__ void kb_split(BNode *nodes, uint32_t begin, uint32_t end, const Bins *bins) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (begin + k >= end) return;
+    BNode &n = nodes[begin + k];
+    if (!node_active(n)) return;
+    const Bins &b = bins[n.bin_slot];
+    float best_cost = FLT_MAX, best_pos = 0.0f;
+    int best_axis = -1;
+    bool empty = false;
+    for (int a = 0; a < 3; ++a) empty = empty || (dec(n.cb_lo[a]) > dec(n.cb_hi[a]));
+    if (!empty) {
+        for (int a = 0; a < 3; ++a) {
+            const float cmin = dec(n.cb_lo[a]), cmax = dec(n.cb_hi[a]);
+            const float extent = cmax - cmin;
+            if (extent <= 0.0f) continue;
+            float left_area[kBins - 1], right_area[kBins - 1];
+            uint32_t left_count[kBins - 1], right_count[kBins - 1];
+            RBox lbox, rbox;
+            lbox.reset();
+            rbox.reset();
+            uint32_t lsum = 0, rsum = 0;
+            for (int i = 0; i < kBins - 1; ++i) {
+                float l[3], h[3];
+                lsum += b.count[a][i];
+                left_count[i] = lsum;
+                for (int c = 0; c < 3; ++c) {  // an untouched bin decodes to the empty box
+                    l[c] = b.count[a][i] ? dec(b.lo[a][i][c]) : FLT_MAX;
+                    h[c] = b.count[a][i] ? dec(b.hi[a][i][c]) : -FLT_MAX;
+                }
+                lbox.grow(l, h);
+                left_area[i] = lbox.area();
+                const int rb = kBins - 1 - i;
+                rsum += b.count[a][rb];
+                right_count[rb - 1] = rsum;
+                for (int c = 0; c < 3; ++c) {
+                    l[c] = b.count[a][rb] ? dec(b.lo[a][rb][c]) : FLT_MAX;
+                    h[c] = b.count[a][rb] ? dec(b.hi[a][rb][c]) : -FLT_MAX;
+                }
+                rbox.grow(l, h);
+                right_area[rb - 1] = rbox.area();
+            }
+            for (int i = 0; i < kBins - 1; ++i) {
+                const float cost = left_count[i] * left_area[i] + right_count[i] * right_area[i];
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = a;
+                    best_pos = cmin + extent * (float(i + 1) / kBins);
+                }
+            }
+        }
+    }
+    RBox nb;
+    for (int a = 0; a < 3; ++a) {
+        nb.lo[a] = n.lo[a];
+        nb.hi[a] = n.hi[a];
+    }
+    const float parent_cost = n.count * nb.area();
+    if (best_axis < 0 || best_cost >= parent_cost) return;
+    n.axis = best_axis;
+    n.pos = best_pos;
+}
+
+__global__ void kb_flags(const BNode *nodes, uint32_t begin, uint32_t end, const uint32_t *node_of, const uint32_t *order, Prims P, uint32_t n, uint32_t *flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = node_of[i];
+    uint32_t f = 0;
+    if (v >= begin && v < end && nodes[v].axis >= 0) f = (P.centroid[nodes[v].axis][order[i]] < nodes[v].pos) ? 0u : 1u;
+    flag[i] = f;
+}
+
+// ---- exclusive prefix sum of n flags into out[0..n] (out[n] = total)
+__global__ __launch_bounds__(kScanBlock) void kb_scan_tiles(const uint32_t *in, uint32_t n, uint32_t *out, uint32_t *tile_sums) {
+    __shared__ uint32_t wave_sum[kScanBlock / 64];
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t v[kScanItems], sum = 0;
+    for (uint32_t k = 0; k < kScanItems; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0u;
+        sum += v[k];
+    }
+    uint32_t incl = sum;  // inclusive scan of the per-thread sums across the wave
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (int(threadIdx.x & 63) >= d) incl += up;
+    }
+    if ((threadIdx.x & 63) == 63) wave_sum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t offset = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) offset += wave_sum[w];
+    uint32_t run = offset + incl - sum;
+    for (uint32_t k = 0; k < kScanItems; ++k) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == kScanBlock - 1) tile_sums[blockIdx.x] = run;
+}
+__global__ __launch_bounds__(1024) void kb_scan_sums(uint32_t *tile_sums, uint32_t tiles, uint32_t *total) {
+    __shared__ uint32_t wave_sum[16];
+    uint32_t v[8], sum = 0;
+    const uint32_t base = threadIdx.x * 8;
+    for (uint32_t k = 0; k < 8; ++k) {
+        v[k] = (base + k < tiles) ? tile_sums[base + k] : 0u;
+        sum += v[k];
+    }
+    uint32_t incl = sum;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (int(threadIdx.x & 63) >= d) incl += up;
+    }
+    if ((threadIdx.x & 63) == 63) wave_sum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t offset = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) offset += wave_sum[w];
+    uint32_t run = offset + incl - sum;
+    for (uint32_t k = 0; k < 8; ++k) {
+        if (base + k < tiles) tile_sums[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == 1023) *total = run;
+}
+__global__ void kb_scan_add(uint32_t *out, uint32_t n, const uint32_t *tile_sums, const uint32_t *total) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] += tile_sums[i / kScanTile];
+    if (i == 0) out[n] = *total;
+}
+
+// Tables of the partition: pfront[first + r] = position of the r-th right-goer from the front,
+// qback[first + l] = position of the l-th left-goer from the back.
+__global__ void kb_rank_tables(const BNode *nodes, uint32_t begin, uint32_t end, const uint32_t *node_of, const uint32_t *flag, const uint32_t *scan, uint32_t n,
+                               uint32_t *pfront, uint32_t *qback) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = node_of[i];
+    if (v < begin || v >= end || nodes[v].axis < 0) return;
+    const uint32_t first = nodes[v].first, count = nodes[v].count;
+    const uint32_t base = scan[first];
+    const uint32_t rights_before = scan[i] - base;
+    if (flag[i]) {
+        pfront[first + rights_before] = i;
+    } else {
+        const uint32_t n_left = count - (scan[first + count] - base);
+        const uint32_t lefts_before = (i - first) - rights_before;
+        qback[first + (n_left - 1 - lefts_before)] = i;
+    }
+}
+
+// The two-cursor partition (bvh.cpp:80-86) examines entries alternately from the front (until
+// it meets a right-goer, which it throws to the back cursor) and from the back (until it meets
+// a left-goer, which lands in the slot just vacated).  With p_r / q_l the tables above:
+//   K  = number of r with p_r < q_r (front and back cursors have not crossed);
+//   K' = K + 1 when one more right-goer is met from the front before the cursors cross;
+//   a left-goer met from the back (back rank l < K) moves to p_l, every other one stays;
+//   a right-goer met from the front (front rank r < K') moves to q_{r-1} - 1 (the last slot for
+//   r = 0), every other one moves one slot towards the front.
+// This kernel finds K and K' per node, allocates the children and names the entries' new owner.
+__global__ void kb_pairs(BNode *nodes, uint32_t begin, uint32_t end, const uint32_t *scan, const uint32_t *pfront, const uint32_t *qback, uint32_t *node_count,
+                         unsigned long long *keys) {
+    const uint32_t v = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= end) return;
+    BNode &n = nodes[v];
+    if (n.axis < 0) return;
+    const uint32_t first = n.first, count = n.count;
+    const uint32_t n_right = scan[first + count] - scan[first], n_left = count - n_right;
+    const uint32_t m = n_right < n_left ? n_right : n_left;
+    uint32_t lo = 0, hi = m;  // smallest r in [0, m] with !(p_r < q_r); the predicate is monotone
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (pfront[first + mid] < qback[first + mid]) lo = mid + 1; else hi = mid;
+    }
+    const uint32_t K = lo;
+    uint32_t K2 = K;
+    if (K < n_right && pfront[first + K] < (K > 0 ? qback[first + K - 1] : first + count)) K2 = K + 1;
+    n.n_right = n_right;
+    n.pairs = K;
+    n.front_rights = K2;
+    if (n_left == 0 || n_left == count) return;  // bvh.cpp:88-89: the list stays permuted, the node stays a leaf
+    const uint32_t left = atomicAdd(node_count, 2u);
+    BNode c = {};
+    c.blas = n.blas;
+    c.axis = -1;
+    c.first = first;
+    c.count = n_left;
+    nodes[left] = c;
+    c.first = first + n_left;
+    c.count = n_right;
+    nodes[left + 1] = c;
+    for (uint32_t s = 0; s < 2; ++s)
+        for (int k = 0; k < 3; ++k) {
+            keys[6 * size_t(left + s) + k] = ~0ull;
+            keys[6 * size_t(left + s) + 3 + k] = 0ull;
+        }
+    n.left = left;
+}
+
+__global__ void kb_scatter(const BNode *nodes, uint32_t begin, uint32_t end, const uint32_t *node_of, const uint32_t *order, const uint32_t *flag, const uint32_t *scan,
+                           const uint32_t *pfront, const uint32_t *qback, uint32_t n, uint32_t *order_out, uint32_t *node_of_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = node_of[i];
+    if (v < begin || v >= end || nodes[v].axis < 0) {
+        order_out[i] = order[i];
+        node_of_out[i] = v;
+        return;
+    }
+    const BNode &nd = nodes[v];
+    const uint32_t first = nd.first, count = nd.count, last = first + count - 1;
+    const uint32_t rights_before = scan[i] - scan[first];
+    const uint32_t n_left = count - nd.n_right;
+    uint32_t dest;
+    if (flag[i]) {
+        const uint32_t r = rights_before;
+        dest = (r < nd.front_rights) ? (r == 0 ? last : qback[first + r - 1] - 1) : i - 1;
+    } else {
+        const uint32_t l = n_left - 1 - ((i - first) - rights_before);
+        dest = (l < nd.pairs) ? pfront[first + l] : i;
+    }
+    order_out[dest] = order[i];
+    node_of_out[dest] = nd.left ? (dest < first + n_left ? nd.left : nd.left + 1) : v;
+}
+
+// ------------------------------------------------------------------ renumbering and output
+__global__ void kb_subtree_sizes(BNode *nodes, uint32_t begin, uint32_t end) {
+    const uint32_t v = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= end) return;
+    BNode &n = nodes[v];
+    n.internal = n.left ? 1u + nodes[n.left].internal + nodes[n.left + 1].internal : 0u;
+}
+__global__ void kb_preorder(BNode *nodes, uint32_t begin, uint32_t end) {
+    const uint32_t v = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= end) return;
+    const BNode &n = nodes[v];
+    if (!n.left) return;
+    BNode &l = nodes[n.left], &r = nodes[n.left + 1];
+    l.index = 1u + 2u * n.rank;
+    r.index = 2u + 2u * n.rank;
+    l.rank = n.rank + 1u;
+    r.rank = n.rank + 1u + l.internal;
+}
+__global__ void kb_emit_nodes(const BNode *nodes, uint32_t node_count, const MeshInfo *meshes, pt_bvh_node *out) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= node_count) return;
+    const BNode &n = nodes[v];
+    const MeshInfo &m = meshes[n.blas];
+    if (m.tri_count == 0) return;
+    pt_bvh_node o;
+    for (int a = 0; a < 3; ++a) {
+        o.min[a] = n.lo[a];
+        o.max[a] = n.hi[a];
+    }
+    if (n.left) {  // child indices are offset into the flattened array (bvh.cpp:245-252)
+        o.first_primitive = m.node_offset + nodes[n.left].index;
+        o.primitive_count = 0;
+    } else {
+        o.first_primitive = n.first - m.tri_first;
+        o.primitive_count = n.count;
+    }
+    out[m.node_offset + n.index] = o;
+}
+__global__ void kb_emit_tris(const uint32_t *order, Prims P, const MeshInfo *meshes, uint32_t n, uint32_t *tri_indices) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t prim = order[i];
+    tri_indices[i] = prim - meshes[P.blas[prim]].tri_first;
+}
+
+// ------------------------------------------------------------------ TLAS
+// World box of an instance: the 8 transformed corners of its mesh's root box (math/aabb.h:50-63).
+__global__ void kb_instance_bounds(const pt_geometry_instance *geoms, uint32_t n, const BNode *nodes, pt_tlas_node *tlas, float *abox, uint32_t *active) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const BNode &root = nodes[geoms[i].blas_index];
+    const float *T = geoms[i].transform;  // column-major
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int c = 0; c < 8; ++c) {
+        const float p[4] = {(c & 1) ? root.hi[0] : root.lo[0], (c & 2) ? root.hi[1] : root.lo[1], (c & 4) ? root.hi[2] : root.lo[2], 1.0f};
+        for (int r = 0; r < 3; ++r) {  // mat4 * vec4 in glm's order: (c0*x + c1*y) + (c2*z + c3*w)
+            const float a = T[0 * 4 + r] * p[0] + T[1 * 4 + r] * p[1];
+            const float b = T[2 * 4 + r] * p[2] + T[3 * 4 + r] * p[3];
+            const float w = a + b;
+            lo[r] = fmin_ref(lo[r], w);
+            hi[r] = fmax_ref(hi[r], w);
+        }
+    }
+    pt_tlas_node t;
+    for (int a = 0; a < 3; ++a) {
+        t.min[a] = lo[a];
+        t.max[a] = hi[a];
+        abox[a * n + i] = lo[a];
+        abox[(3 + a) * n + i] = hi[a];
+    }
+    t.instance = i;
+    t.left_right = 0;
+    tlas[1 + i] = t;  // slot 0 is the root's copy, leaves sit at 1..n in instance order (bvh.cpp:266-281)
+    active[i] = 1 + i;
+}
+
+// bvh.cpp:283-331.  abox = boxes of the live clusters, structure of arrays with stride n.
+// status[0] = 0 on success, 1 when the iteration guard tripped.
+constexpr uint32_t kTlasThreads = 1024;
+__global__ __launch_bounds__(kTlasThreads) void kb_tlas_pairing(pt_tlas_node *tlas, float *abox, uint32_t *active, uint32_t n, uint32_t *status) {
+    __shared__ float s_area[kTlasThreads / 64];
+    __shared__ int s_index[kTlasThreads / 64];
+    __shared__ int s_result;
+    const uint32_t tid = threadIdx.x;
+    int live = int(n);
+    uint32_t next_node = 1 + n;
+
+    // Cluster of smallest merged area with cluster `who`; the lowest slot wins ties (strict < in a
+    // forward scan, bvh.cpp:286-297).  Every thread returns the same value.
+    auto best_partner = [&](int who) -> int {
+        float mine_lo[3], mine_hi[3];
+        for (int a = 0; a < 3; ++a) {
+            mine_lo[a] = abox[a * n + who];
+            mine_hi[a] = abox[(3 + a) * n + who];
+        }
+        float best_area = FLT_MAX;
+        int best = -1;
+        for (int j = int(tid); j < live; j += int(kTlasThreads)) {
+            if (j == who) continue;
+            RBox m;
+            for (int a = 0; a < 3; ++a) {
+                m.lo[a] = fmin_ref(mine_lo[a], abox[a * n + j]);
+                m.hi[a] = fmax_ref(mine_hi[a], abox[(3 + a) * n + j]);
+            }
+            const float area = m.area();
+            if (area < best_area) {
+                best_area = area;
+                best = j;
+            }
+        }
+        // a candidate beats another when its area is smaller, or equal with a lower slot;
+        // "no candidate" (-1) never beats a candidate
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float oa = __shfl_xor(best_area, d, 64);
+            const int ob = __shfl_xor(best, d, 64);
+            const bool take = ob >= 0 && (best < 0 || oa < best_area || (oa == best_area && ob < best));
+            if (take) {
+                best_area = oa;
+                best = ob;
+            }
+        }
+        if ((tid & 63) == 0) {
+            s_area[tid >> 6] = best_area;
+            s_index[tid >> 6] = best;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float ba = s_area[0];
+            int bi = s_index[0];
+            for (uint32_t w = 1; w < kTlasThreads / 64; ++w) {
+                const float oa = s_area[w];
+                const int ob = s_index[w];
+                if (ob >= 0 && (bi < 0 || oa < ba || (oa == ba && ob < bi))) {
+                    ba = oa;
+                    bi = ob;
+                }
+            }
+            s_result = bi;
+        }
+        __syncthreads();
+        const int r = s_result;
+        __syncthreads();  // s_result is rewritten by the next search
+        return r;
+    };
+
+    int a = 0;
+    int b = (live > 1) ? best_partner(a) : -1;
+    // every step either merges (live shrinks) or walks the chain to a pair of smaller merged
+    // area; the guard only stops a walk that would never end on malformed (NaN) boxes
+    unsigned long long guard = 64ull * n + 1024ull;
+    bool failed = false;
+    while (live > 1) {
+        if (guard-- == 0 || b < 0) {
+            failed = true;
+            break;
+        }
+        const int c = best_partner(b);
+        if (a == c) {
+            if (tid == 0) {
+                pt_tlas_node t;
+                for (int k = 0; k < 3; ++k) {
+                    t.min[k] = fmin_ref(abox[k * n + a], abox[k * n + b]);
+                    t.max[k] = fmax_ref(abox[(3 + k) * n + a], abox[(3 + k) * n + b]);
+                }
+                t.instance = 0;
+                t.left_right = active[a] | (active[b] << 16);
+                tlas[next_node] = t;
+                active[a] = next_node;
+                active[b] = active[live - 1];
+                for (int k = 0; k < 3; ++k) {
+                    abox[k * n + a] = t.min[k];
+                    abox[(3 + k) * n + a] = t.max[k];
+                }
+                for (int k = 0; k < 6; ++k) abox[k * n + b] = abox[k * n + (live - 1)];
+            }
+            ++next_node;
+            --live;
+            __threadfence_block();
+            __syncthreads();
+            b = (live > 1) ? best_partner(a) : -1;
+        } else {
+            a = b;
+            b = c;
+        }
+    }
+    if (tid == 0) {
+        tlas[0] = tlas[active[a]];
+        status[0] = failed ? 1u : 0u;
+    }
+}
+
+// ------------------------------------------------------------------ host driver
+struct BuildResult {
+    std::vector<pt_tlas_node> tlas_nodes;
+    std::vector<pt_blas> blases;
+    std::vector<pt_bvh_node> blas_nodes;
+    std::vector<uint32_t> tri_indices;
+    uint32_t levels = 0;
+    float ms_blas = 0.0f, ms_tlas = 0.0f;  // device time of the two parts
+};
+
+struct DeviceArena {  // frees everything it handed out
+    std::vector<void *> blocks;
+    ~DeviceArena() {
+        for (void *p : blocks) (void)hipFree(p);
+    }
+    template <typename T>
+    hipError_t get(T **out, size_t count) {
+        void *p = nullptr;
+        const hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) blocks.push_back(p);
+        *out = static_cast<T *>(p);
+        return e;
+    }
+};
+
+#define PTB_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        const hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                         \
+            err = std::string(#expr) + ": " + hipGetErrorString(e_);                                    \
+            return PT_ERR_DEVICE;                                                                       \
+        }                                                                                               \
+    } while (0)
+
+inline uint32_t Blocks(uint32_t n, uint32_t per = 256) { return (n + per - 1) / per; }
+
+// TLAS::Build (bvh.cpp:204-332) for host arrays in the reference's layouts.
+inline int BuildOnDevice(hipStream_t stream, const float *positions, uint32_t vertex_count, const uint32_t *indices, uint32_t index_count,
+                         const pt_geometry_instance *geoms, uint32_t geom_count, BuildResult &out, std::string &err) {
+    if (geom_count == 0) {
+        err = "a scene needs at least one geometry instance";
+        return PT_ERR_INVALID;
+    }
+    if (2ull * geom_count - 1 > 65535) {  // kernel/device_types.h:153-154
+        err = "more than 32767 instances do not fit the TLAS's 16-bit child indices";
+        return PT_ERR_LIMIT;
+    }
+    // ---- one mesh per distinct blas_index, defined by the first instance that names it (bvh.cpp:216-236)
+    int max_mesh = 0;
+    for (uint32_t i = 0; i < geom_count; ++i) {
+        if (geoms[i].blas_index < 0) {
+            err = "instance without blas_index";
+            return PT_ERR_INVALID;
+        }
+        max_mesh = std::max(max_mesh, geoms[i].blas_index);
+    }
+    const uint32_t mesh_count = uint32_t(max_mesh) + 1;
+    std::vector<MeshInfo> meshes(mesh_count, MeshInfo{0, 0, 0, 0});
+    std::vector<char> seen(mesh_count, 0);
+    for (uint32_t i = 0; i < geom_count; ++i) {
+        const pt_geometry_instance &g = geoms[i];
+        if (seen[g.blas_index]) continue;
+        seen[g.blas_index] = 1;
+        if (g.index_count / 3u == 0) {
+            err = "instance with an empty mesh";
+            return PT_ERR_INVALID;
+        }
+        if (uint64_t(g.first_index) + (g.index_count / 3u) * 3ull > index_count) {
+            err = "mesh index range exceeds the index array";
+            return PT_ERR_INVALID;
+        }
+        meshes[g.blas_index].first_index = g.first_index;
+        meshes[g.blas_index].tri_count = g.index_count / 3u;
+    }
+    uint64_t total = 0;
+    for (MeshInfo &m : meshes) {
+        m.tri_first = uint32_t(total);
+        total += m.tri_count;
+    }
+    if (total > kMaxPrims) {
+        err = "more than 2^24 triangles in one build";
+        return PT_ERR_LIMIT;
+    }
+    const uint32_t n = uint32_t(total);
+    for (uint32_t i = 0; i < index_count; ++i)
+        if (indices[i] >= vertex_count) {
+            err = "vertex index out of range";
+            return PT_ERR_INVALID;
+        }
+
+    DeviceArena mem;
+    float *d_positions;
+    uint32_t *d_indices;
+    pt_geometry_instance *d_geoms;
+    MeshInfo *d_meshes;
+    PTB_TRY(mem.get(&d_positions, size_t(vertex_count) * 3));
+    PTB_TRY(mem.get(&d_indices, index_count));
+    PTB_TRY(mem.get(&d_geoms, geom_count));
+    PTB_TRY(mem.get(&d_meshes, mesh_count));
+    PTB_TRY(hipMemcpyAsync(d_positions, positions, size_t(vertex_count) * 12, hipMemcpyHostToDevice, stream));
+    PTB_TRY(hipMemcpyAsync(d_indices, indices, size_t(index_count) * 4, hipMemcpyHostToDevice, stream));
+    PTB_TRY(hipMemcpyAsync(d_geoms, geoms, size_t(geom_count) * sizeof(pt_geometry_instance), hipMemcpyHostToDevice, stream));
+    PTB_TRY(hipMemcpyAsync(d_meshes, meshes.data(), size_t(mesh_count) * sizeof(MeshInfo), hipMemcpyHostToDevice, stream));
+
+    Prims P;
+    for (int a = 0; a < 3; ++a) {
+        PTB_TRY(mem.get(&P.lo[a], n));
+        PTB_TRY(mem.get(&P.hi[a], n));
+        PTB_TRY(mem.get(&P.centroid[a], n));
+    }
+    PTB_TRY(mem.get(&P.blas, n));
+    const size_t max_nodes = 2 * size_t(n) + mesh_count;
+    const size_t max_active = size_t(n) / 3 + mesh_count;
+    uint32_t *order[2], *node_of[2], *flag, *scan, *pfront, *qback, *tile_sums, *counters;
+    BNode *nodes;
+    Bins *bins;
+    unsigned long long *keys;
+    for (int k = 0; k < 2; ++k) {
+        PTB_TRY(mem.get(&order[k], n));
+        PTB_TRY(mem.get(&node_of[k], n));
+    }
+    PTB_TRY(mem.get(&flag, n));
+    PTB_TRY(mem.get(&scan, size_t(n) + 1));
+    PTB_TRY(mem.get(&pfront, n));
+    PTB_TRY(mem.get(&qback, n));
+    PTB_TRY(mem.get(&tile_sums, 8192));
+    PTB_TRY(mem.get(&counters, 4));  // [0] node count, [1] scan total, [2] TLAS status, [3] bin slots of the pass
+    PTB_TRY(mem.get(&nodes, max_nodes));
+    PTB_TRY(mem.get(&bins, max_active));
+    PTB_TRY(mem.get(&keys, max_nodes * 6));
+
+    hipEvent_t ev[3];
+    for (hipEvent_t &e : ev) PTB_TRY(hipEventCreate(&e));
+    struct EventGuard {
+        hipEvent_t *e;
+        ~EventGuard() {
+            for (int k = 0; k < 3; ++k) (void)hipEventDestroy(e[k]);
+        }
+    } event_guard{ev};
+    PTB_TRY(hipEventRecord(ev[0], stream));
+
+    hipLaunchKernelGGL(kb_prims, dim3(Blocks(n)), dim3(256), 0, stream, d_positions, d_indices, d_meshes, mesh_count, P, n, order[0], node_of[0]);
+    hipLaunchKernelGGL(kb_roots, dim3(Blocks(mesh_count)), dim3(256), 0, stream, nodes, d_meshes, mesh_count, keys);
+    hipLaunchKernelGGL(kb_bounds_keys, dim3(Blocks(n)), dim3(256), 0, stream, nodes, 0u, mesh_count, node_of[0], order[0], P, n, keys);
+    hipLaunchKernelGGL(kb_bounds_decode, dim3(Blocks(mesh_count)), dim3(256), 0, stream, nodes, 0u, mesh_count, keys, order[0], P);
+    uint32_t node_count = mesh_count;
+    PTB_TRY(hipMemcpyAsync(counters, &node_count, 4, hipMemcpyHostToDevice, stream));
+
+    std::vector<std::pair<uint32_t, uint32_t>> levels;
+    uint32_t begin = 0, end = mesh_count;
+    int cur = 0;
+    const uint32_t tiles = Blocks(n, kScanTile);
+    while (begin < end) {
+        levels.emplace_back(begin, end);
+        const uint32_t width = end - begin;
+        PTB_TRY(hipMemsetAsync(counters + 3, 0, 4, stream));
+        hipLaunchKernelGGL(kb_level_init, dim3(Blocks(width)), dim3(256), 0, stream, nodes, begin, end, bins, counters + 3);
+        hipLaunchKernelGGL(kb_centroid_bounds, dim3(Blocks(n)), dim3(256), 0, stream, nodes, begin, end, node_of[cur], order[cur], P, n);
+        hipLaunchKernelGGL(kb_bin, dim3(Blocks(n)), dim3(256), 0, stream, nodes, begin, end, node_of[cur], order[cur], P, n, bins);
+        hipLaunchKernelGGL(kb_split, dim3(Blocks(width, 64)), dim3(64), 0, stream, nodes, begin, end, bins);
+        hipLaunchKernelGGL(kb_flags, dim3(Blocks(n)), dim3(256), 0, stream, nodes, begin, end, node_of[cur], order[cur], P, n, flag);
+        hipLaunchKernelGGL(kb_scan_tiles, dim3(tiles), dim3(kScanBlock), 0, stream, flag, n, scan, tile_sums);
+        hipLaunchKernelGGL(kb_scan_sums, dim3(1), dim3(1024), 0, stream, tile_sums, tiles, counters + 1);
+        hipLaunchKernelGGL(kb_scan_add, dim3(Blocks(n)), dim3(256), 0, stream, scan, n, tile_sums, counters + 1);
+        hipLaunchKernelGGL(kb_rank_tables, dim3(Blocks(n)), dim3(256), 0, stream, nodes, begin, end, node_of[cur], flag, scan, n, pfront, qback);
+        hipLaunchKernelGGL(kb_pairs, dim3(Blocks(width, 64)), dim3(64), 0, stream, nodes, begin, end, scan, pfront, qback, counters, keys);
+        hipLaunchKernelGGL(kb_scatter, dim3(Blocks(n)), dim3(256), 0, stream, nodes, begin, end, node_of[cur], order[cur], flag, scan, pfront, qback, n,
+                           order[cur ^ 1], node_of[cur ^ 1]);
+        cur ^= 1;
+        PTB_TRY(hipMemcpyAsync(&node_count, counters, 4, hipMemcpyDeviceToHost, stream));
+        PTB_TRY(hipStreamSynchronize(stream));
+        if (node_count > max_nodes) {
+            err = "internal: node storage exceeded";
+            return PT_ERR_DEVICE;
+        }
+        begin = end;
+        end = node_count;
+        if (begin < end) {
+            hipLaunchKernelGGL(kb_bounds_keys, dim3(Blocks(n)), dim3(256), 0, stream, nodes, begin, end, node_of[cur], order[cur], P, n, keys);
+            hipLaunchKernelGGL(kb_bounds_decode, dim3(Blocks(end - begin)), dim3(256), 0, stream, nodes, begin, end, keys, order[cur], P);
+        }
+    }
+    out.levels = uint32_t(levels.size());
+
+    // ---- renumber: subtree sizes bottom-up, preorder ranks top-down
+    for (size_t l = levels.size(); l-- > 0;)
+        hipLaunchKernelGGL(kb_subtree_sizes, dim3(Blocks(levels[l].second - levels[l].first)), dim3(256), 0, stream, nodes, levels[l].first, levels[l].second);
+    for (size_t l = 0; l < levels.size(); ++l)
+        hipLaunchKernelGGL(kb_preorder, dim3(Blocks(levels[l].second - levels[l].first)), dim3(256), 0, stream, nodes, levels[l].first, levels[l].second);
+    std::vector<BNode> roots(mesh_count);
+    PTB_TRY(hipMemcpyAsync(roots.data(), nodes, size_t(mesh_count) * sizeof(BNode), hipMemcpyDeviceToHost, stream));
+    PTB_TRY(hipStreamSynchronize(stream));
+    out.blases.assign(mesh_count, pt_blas{0, 0, 0, 0});
+    uint32_t node_total = 0;
+    for (uint32_t b = 0; b < mesh_count; ++b) {
+        if (meshes[b].tri_count == 0) continue;  // unused blas_index: an all-zero DeviceBLAS (bvh.cpp:238-264)
+        const uint32_t mesh_nodes = 1 + 2 * roots[b].internal;
+        meshes[b].node_offset = node_total;
+        out.blases[b] = pt_blas{node_total, mesh_nodes, meshes[b].tri_first, meshes[b].tri_count};
+        node_total += mesh_nodes;
+    }
+    PTB_TRY(hipMemcpyAsync(d_meshes, meshes.data(), size_t(mesh_count) * sizeof(MeshInfo), hipMemcpyHostToDevice, stream));
+    pt_bvh_node *d_out_nodes;
+    uint32_t *d_out_tris;
+    PTB_TRY(mem.get(&d_out_nodes, node_total));
+    PTB_TRY(mem.get(&d_out_tris, n));
+    hipLaunchKernelGGL(kb_emit_nodes, dim3(Blocks(node_count)), dim3(256), 0, stream, nodes, node_count, d_meshes, d_out_nodes);
+    hipLaunchKernelGGL(kb_emit_tris, dim3(Blocks(n)), dim3(256), 0, stream, order[cur], P, d_meshes, n, d_out_tris);
+    PTB_TRY(hipEventRecord(ev[1], stream));
+
+    // ---- TLAS
+    pt_tlas_node *d_tlas;
+    float *d_abox;
+    uint32_t *d_active;
+    PTB_TRY(mem.get(&d_tlas, 2 * size_t(geom_count)));
+    PTB_TRY(mem.get(&d_abox, 6 * size_t(geom_count)));
+    PTB_TRY(mem.get(&d_active, geom_count));
+    hipLaunchKernelGGL(kb_instance_bounds, dim3(Blocks(geom_count)), dim3(256), 0, stream, d_geoms, geom_count, nodes, d_tlas, d_abox, d_active);
+    hipLaunchKernelGGL(kb_tlas_pairing, dim3(1), dim3(kTlasThreads), 0, stream, d_tlas, d_abox, d_active, geom_count, counters + 2);
+    PTB_TRY(hipEventRecord(ev[2], stream));
+    PTB_TRY(hipGetLastError());
+
+    out.blas_nodes.resize(node_total);
+    out.tri_indices.resize(n);
+    out.tlas_nodes.resize(2 * size_t(geom_count));
+    uint32_t tlas_status = 0;
+    PTB_TRY(hipMemcpyAsync(out.blas_nodes.data(), d_out_nodes, size_t(node_total) * sizeof(pt_bvh_node), hipMemcpyDeviceToHost, stream));
+    PTB_TRY(hipMemcpyAsync(out.tri_indices.data(), d_out_tris, size_t(n) * 4, hipMemcpyDeviceToHost, stream));
+    PTB_TRY(hipMemcpyAsync(out.tlas_nodes.data(), d_tlas, out.tlas_nodes.size() * sizeof(pt_tlas_node), hipMemcpyDeviceToHost, stream));
+    PTB_TRY(hipMemcpyAsync(&tlas_status, counters + 2, 4, hipMemcpyDeviceToHost, stream));
+    PTB_TRY(hipStreamSynchronize(stream));
+    if (tlas_status != 0) {
+        err = "TLAS pairing did not converge (non-finite instance bounds?)";
+        return PT_ERR_INVALID;
+    }
+    (void)hipEventElapsedTime(&out.ms_blas, ev[0], ev[1]);
+    (void)hipEventElapsedTime(&out.ms_tlas, ev[1], ev[2]);
+    return PT_OK;
+}
+
+}  // namespace ptb

@@ -13,6 +13,7 @@
 #include "../../include/ptamd.h"
 #include "kernels.h"
 #include "debug_view.h"
+#include "bvh_build.h"
 #ifndef PT_WAVES_PER_CU
 #define PT_WAVES_PER_CU 16  // persistent waves per CU (4 per SIMD)
 #endif
@@ -1203,6 +1204,54 @@ int pt_debug_render(pt_ctx *ctx, int width, int height, const pt_integrator_stat
     HIP_TRY(ctx, hipGetLastError());
     return PT_OK;
 }
+
+// ------------------------------------------------------------------ device BVH build
+struct pt_bvh {
+    ptb::BuildResult r;
+};
+
+// TLAS::Build / BLAS::Build (bvh.cpp:5-332) on the device; host arrays in, host arrays out.
+int pt_bvh_build(pt_ctx *ctx, const float *positions, uint32_t vertex_count, const uint32_t *indices, uint32_t index_count,
+                 const pt_geometry_instance *geometries, uint32_t geometry_count, pt_bvh **out) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!out) return Fail(ctx, PT_ERR_INVALID, "pt_bvh_build: null output");
+    *out = nullptr;
+    if (!positions || !indices || !geometries) return Fail(ctx, PT_ERR_INVALID, "pt_bvh_build: null input array");
+    DeviceGuard guard(ctx->device);
+    pt_bvh *h = new pt_bvh();
+    std::string err;
+    const int st = ptb::BuildOnDevice(ctx->stream, positions, vertex_count, indices, index_count, geometries, geometry_count, h->r, err);
+    if (st != PT_OK) {
+        delete h;
+        return Fail(ctx, st, "pt_bvh_build: %s", err.c_str());
+    }
+    *out = h;
+    return PT_OK;
+}
+int pt_bvh_sizes(const pt_bvh *bvh, uint32_t *tlas_nodes, uint32_t *blases, uint32_t *blas_nodes, uint32_t *tri_indices) {
+    if (!bvh) return PT_ERR_INVALID;
+    if (tlas_nodes) *tlas_nodes = uint32_t(bvh->r.tlas_nodes.size());
+    if (blases) *blases = uint32_t(bvh->r.blases.size());
+    if (blas_nodes) *blas_nodes = uint32_t(bvh->r.blas_nodes.size());
+    if (tri_indices) *tri_indices = uint32_t(bvh->r.tri_indices.size());
+    return PT_OK;
+}
+int pt_bvh_get(const pt_bvh *bvh, pt_tlas_node *tlas_nodes, pt_blas *blases, pt_bvh_node *blas_nodes, uint32_t *tri_indices) {
+    if (!bvh) return PT_ERR_INVALID;
+    if (tlas_nodes) std::memcpy(tlas_nodes, bvh->r.tlas_nodes.data(), bvh->r.tlas_nodes.size() * sizeof(pt_tlas_node));
+    if (blases) std::memcpy(blases, bvh->r.blases.data(), bvh->r.blases.size() * sizeof(pt_blas));
+    if (blas_nodes) std::memcpy(blas_nodes, bvh->r.blas_nodes.data(), bvh->r.blas_nodes.size() * sizeof(pt_bvh_node));
+    if (tri_indices) std::memcpy(tri_indices, bvh->r.tri_indices.data(), bvh->r.tri_indices.size() * sizeof(uint32_t));
+    return PT_OK;
+}
+int pt_bvh_timing(const pt_bvh *bvh, float *ms_blas, float *ms_tlas, uint32_t *levels) {
+    if (!bvh) return PT_ERR_INVALID;
+    if (ms_blas) *ms_blas = bvh->r.ms_blas;
+    if (ms_tlas) *ms_tlas = bvh->r.ms_tlas;
+    if (levels) *levels = bvh->r.levels;
+    return PT_OK;
+}
+void pt_bvh_free(pt_bvh *bvh) { delete bvh; }
 
 }  // extern "C"
 

@@ -370,6 +370,27 @@ class Context:
         """DebugIntegrator::Render (debug.cu:198-239): BVH heat map or attribute view; asynchronous."""
         self._check(self._lib.pt_debug_render(self._h, w, h, C.byref(state), C.c_void_p(image_ptr), C.c_void_p(rgba_ptr)))
 
+    def bvh_build(self, positions: np.ndarray, indices: np.ndarray, geometries: np.ndarray, timing: bool = False):
+        """TLAS::Build (bvh.cpp:204-332) on the GPU -> dict of reference-layout host arrays, identical to bvh_build()."""
+        pos = np.ascontiguousarray(positions, np.float32).reshape(-1)
+        idx = np.ascontiguousarray(indices, np.uint32)
+        geo = np.ascontiguousarray(geometries, abi.GEOMETRY)
+        h = C.c_void_p()
+        self._check(self._lib.pt_bvh_build(self._h, abi.fptr(pos), len(pos) // 3, abi.uptr(idx), len(idx), abi.vptr(geo), len(geo), C.byref(h)))
+        try:
+            n = [C.c_uint32() for _ in range(4)]
+            self._lib.pt_bvh_sizes(h, *[C.byref(x) for x in n])
+            out = {"tlas_nodes": np.zeros(n[0].value, abi.TLAS_NODE), "blases": np.zeros(n[1].value, abi.BLAS),
+                   "blas_nodes": np.zeros(n[2].value, abi.BVH_NODE), "tri_indices": np.zeros(n[3].value, np.uint32)}
+            self._lib.pt_bvh_get(h, abi.vptr(out["tlas_nodes"]), abi.vptr(out["blases"]), abi.vptr(out["blas_nodes"]), abi.vptr(out["tri_indices"]))
+            if timing:
+                ms_blas, ms_tlas, levels = C.c_float(), C.c_float(), C.c_uint32()
+                self._lib.pt_bvh_timing(h, C.byref(ms_blas), C.byref(ms_tlas), C.byref(levels))
+                out["timing"] = {"ms_blas": ms_blas.value, "ms_tlas": ms_tlas.value, "levels": levels.value}
+            return out
+        finally:
+            self._lib.pt_bvh_free(h)
+
     # batch queries on device pointers
     def trace_closest(self, rays_ptr: int, n: int, hits_ptr: int):
         self._check(self._lib.pt_trace_closest(self._h, C.c_void_p(rays_ptr), n, C.c_void_p(hits_ptr)))

@@ -358,6 +358,30 @@ typedef struct pt_integrator_state {
 int pt_debug_render(pt_ctx *ctx, int width, int height, const pt_integrator_state *state,
                     float *image_device, uint8_t *rgba_device);
 
+/* ------------------------------------------------------------ device BVH build */
+
+/* Replaces TLAS::Build and the BLAS::Build calls inside it (bvh.cpp:5-332) with a build on the
+ * GPU: one binned-SAH BLAS per distinct blas_index (defined by the first instance naming it),
+ * instance world bounds, agglomerative TLAS.  Inputs are HOST arrays in the reference's
+ * layouts (Scene::Positions / Indices, GeometryInstance[] with transform, first_index,
+ * index_count and blas_index filled); the result is read back into HOST arrays identical, bit
+ * for bit, to what the reference's sequential builder produces (node numbering and triangle
+ * permutation included), ready for pt_scene_desc.  Limits: 32767 instances (16-bit TLAS child
+ * indices, kernel/device_types.h:153-154), 2^24 triangles per call.  Synchronous.            */
+typedef struct pt_bvh pt_bvh;
+int pt_bvh_build(pt_ctx *ctx, const float *positions, uint32_t vertex_count, const uint32_t *indices,
+                 uint32_t index_count, const pt_geometry_instance *geometries, uint32_t geometry_count,
+                 pt_bvh **out);
+/* Array lengths of the result (TLAS::UpdateDevice, bvh.cpp:334-352). */
+int pt_bvh_sizes(const pt_bvh *bvh, uint32_t *tlas_nodes, uint32_t *blases, uint32_t *blas_nodes,
+                 uint32_t *tri_indices);
+/* Copies the result into caller arrays of those lengths (any may be NULL). */
+int pt_bvh_get(const pt_bvh *bvh, pt_tlas_node *tlas_nodes, pt_blas *blases, pt_bvh_node *blas_nodes,
+               uint32_t *tri_indices);
+/* Device time of the BLAS and TLAS parts (ms) and the depth of the deepest BLAS. */
+int pt_bvh_timing(const pt_bvh *bvh, float *ms_blas, float *ms_tlas, uint32_t *levels);
+void pt_bvh_free(pt_bvh *bvh);
+
 /* ------------------------------------------------- batch ray queries (metric) */
 
 /* IntersectScene<CLOSEST> (kernel/intersection.h:154-235) over n rays.
