@@ -17,6 +17,11 @@
 //   * nodes are numbered breadth first while building and renumbered at the end: the reference
 //     allocates a node's two children when it subdivides the node, in depth-first order, so
 //     the left child of the k-th subdivided node (preorder) is node 1 + 2k.
+// Nodes of more than kSmall triangles are processed that way.  A node of kSmall triangles or fewer
+// is handed, with its whole subtree, to one wave that keeps the triangles in LDS and walks the
+// subtree depth first like the reference (reductions across the lanes, the plane sweep and the
+// two-cursor partition on one lane): thousands of such subtrees run side by side, and the many
+// tiny nodes at the bottom of a tree cost no passes over the whole array.
 // The TLAS pairing loop (bvh.cpp:283-331) is a chain of arg-min searches, each depending on
 // the previous merge; one workgroup runs the chain with every search spread over its lanes.
 #pragma once
@@ -33,6 +38,7 @@
 namespace ptb {
 
 constexpr int kBins = 8;
+constexpr uint32_t kSmall = 256;  // subtrees of this many triangles or fewer are built by one wave
 constexpr uint32_t kScanBlock = 256, kScanItems = 8, kScanTile = kScanBlock * kScanItems;
 constexpr uint32_t kMaxPrims = kScanTile * 8192u;  // one level of block sums is scanned by a single block
 
@@ -64,6 +70,9 @@ struct BNode {  // build-time node, breadth-first numbering; roots are nodes 0..
     uint32_t internal;            // subdivided nodes in the subtree (itself included)
     uint32_t rank;                // preorder rank among its mesh's subdivided nodes
     uint32_t index;               // final index inside its mesh's node array
+    uint32_t small;               // 1: root of a subtree built by one wave
+    uint32_t owner, local;        // nodes inside such a subtree: its root, and the node's number in the
+                                  // subtree's own depth-first numbering (root 0)
 };
 
 struct Bins {  // 8 bins on each axis: enc()-coded boxes and counts
@@ -113,7 +122,7 @@ __global__ void kb_prims(const float *positions, const uint32_t *indices, const 
     node_of[g] = lo;
 }
 
-__global__ void kb_roots(BNode *nodes, const MeshInfo *meshes, uint32_t mesh_count, unsigned long long *keys) {
+__global__ void kb_roots(BNode *nodes, const MeshInfo *meshes, uint32_t mesh_count, unsigned long long *keys, uint32_t *small_list, uint32_t *small_count) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= mesh_count) return;
     BNode n = {};
@@ -121,6 +130,10 @@ __global__ void kb_roots(BNode *nodes, const MeshInfo *meshes, uint32_t mesh_cou
     n.count = meshes[b].tri_count;
     n.blas = b;
     n.axis = -1;
+    if (n.count > 0 && n.count <= kSmall) {
+        n.small = 1;
+        small_list[atomicAdd(small_count, 1u)] = b;
+    }
     nodes[b] = n;
     for (int k = 0; k < 3; ++k) {
         keys[6 * size_t(b) + k] = ~0ull;
@@ -128,17 +141,62 @@ __global__ void kb_roots(BNode *nodes, const MeshInfo *meshes, uint32_t mesh_cou
     }
 }
 
+// True when all 64 lanes of the wave are live and hold the same value (then one lane can speak
+// for the wave after a reduction across the lanes).
+PTB_D bool wave_uniform(bool live, uint32_t v) {
+    const uint32_t v0 = __builtin_amdgcn_readfirstlane(v);
+    return __ballot(live && v == v0) == ~0ull;
+}
+PTB_D uint32_t wave_min(uint32_t x) {
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = __shfl_xor(x, d, 64);
+        x = o < x ? o : x;
+    }
+    return x;
+}
+PTB_D uint32_t wave_max(uint32_t x) {
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = __shfl_xor(x, d, 64);
+        x = o > x ? o : x;
+    }
+    return x;
+}
+PTB_D unsigned long long wave_min64(unsigned long long x) {
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(x, d, 64);
+        x = o < x ? o : x;
+    }
+    return x;
+}
+PTB_D unsigned long long wave_max64(unsigned long long x) {
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(x, d, 64);
+        x = o > x ? o : x;
+    }
+    return x;
+}
+
 // Box of the nodes [begin, end): union of the boxes of their entries, as (value, position) keys.
+// A node's entries are contiguous, so most waves lie inside one node and send one atomic per
+// value instead of 64 to the same address.
 __global__ void kb_bounds_keys(const BNode *nodes, uint32_t begin, uint32_t end, const uint32_t *node_of, const uint32_t *order, Prims P, uint32_t n,
                                unsigned long long *keys) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t v = node_of[i];
-    if (v < begin || v >= end) return;
-    const uint32_t prim = order[i];
+    const uint32_t v = i < n ? node_of[i] : 0xFFFFFFFFu;
+    const bool live = i < n && v >= begin && v < end;
+    const uint32_t prim = live ? order[i] : 0u;
+    const bool uniform = wave_uniform(live, v);
+    if (!uniform && !live) return;
     for (int a = 0; a < 3; ++a) {
-        atomicMin(&keys[6 * size_t(v) + a], ((unsigned long long)enc_eq(P.lo[a][prim]) << 32) | i);
-        atomicMax(&keys[6 * size_t(v) + 3 + a], ((unsigned long long)enc_eq(P.hi[a][prim]) << 32) | (0xFFFFFFFFu - i));
+        unsigned long long klo = ((unsigned long long)enc_eq(P.lo[a][prim]) << 32) | i;
+        unsigned long long khi = ((unsigned long long)enc_eq(P.hi[a][prim]) << 32) | (0xFFFFFFFFu - i);
+        if (uniform) {
+            klo = wave_min64(klo);
+            khi = wave_max64(khi);
+            if ((threadIdx.x & 63) != 0) continue;
+        }
+        atomicMin(&keys[6 * size_t(v) + a], klo);
+        atomicMax(&keys[6 * size_t(v) + 3 + a], khi);
     }
 }
 __global__ void kb_bounds_decode(BNode *nodes, uint32_t begin, uint32_t end, const unsigned long long *keys, const uint32_t *order, Prims P) {
@@ -153,7 +211,7 @@ __global__ void kb_bounds_decode(BNode *nodes, uint32_t begin, uint32_t end, con
 }
 
 // ------------------------------------------------------------------ one pass over a level
-PTB_D bool node_active(const BNode &n) { return n.count > 2; }  // bvh.cpp:69
+PTB_D bool node_active(const BNode &n) { return n.count > kSmall; }  // smaller nodes belong to a single-wave subtree
 
 __global__ void kb_level_init(BNode *nodes, uint32_t begin, uint32_t end, Bins *bins, uint32_t *slot_counter) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -165,7 +223,7 @@ __global__ void kb_level_init(BNode *nodes, uint32_t begin, uint32_t end, Bins *
         n.cb_lo[a] = 0xFFFFFFFFu;
         n.cb_hi[a] = 0u;
     }
-    n.bin_slot = atomicAdd(slot_counter, 1u);  // at most (triangles / 3) nodes of a level hold 3 or more
+    n.bin_slot = atomicAdd(slot_counter, 1u);  // at most (triangles / kSmall) nodes of a level are this large
     Bins &b = bins[n.bin_slot];
     for (int a = 0; a < 3; ++a)
         for (int j = 0; j < kBins; ++j) {
@@ -179,26 +237,45 @@ __global__ void kb_level_init(BNode *nodes, uint32_t begin, uint32_t end, Bins *
 
 __global__ void kb_centroid_bounds(BNode *nodes, uint32_t begin, uint32_t end, const uint32_t *node_of, const uint32_t *order, Prims P, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t v = node_of[i];
-    if (v < begin || v >= end || !node_active(nodes[v])) return;
-    const uint32_t prim = order[i];
+    const uint32_t v = i < n ? node_of[i] : 0xFFFFFFFFu;
+    const bool live = i < n && v >= begin && v < end && node_active(nodes[v]);
+    const uint32_t prim = live ? order[i] : 0u;
+    const bool uniform = wave_uniform(live, v);
+    if (!uniform && !live) return;
     for (int a = 0; a < 3; ++a) {
-        const uint32_t e = enc(P.centroid[a][prim]);
-        atomicMin(&nodes[v].cb_lo[a], e);
-        atomicMax(&nodes[v].cb_hi[a], e);
+        uint32_t lo = enc(P.centroid[a][prim]), hi = lo;
+        if (uniform) {
+            lo = wave_min(lo);
+            hi = wave_max(hi);
+            if ((threadIdx.x & 63) != 0) continue;
+        }
+        atomicMin(&nodes[v].cb_lo[a], lo);
+        atomicMax(&nodes[v].cb_hi[a], hi);
     }
 }
 
 // bvh.cpp:151-165: bin index of a centroid on every axis whose centroid extent is positive.
-__global__ void kb_bin(const BNode *nodes, uint32_t begin, uint32_t end, const uint32_t *node_of, const uint32_t *order, Prims P, uint32_t n, Bins *bins) {
+// A wave that lies inside one node bins into LDS first and sends each touched bin once.
+__global__ __launch_bounds__(256) void kb_bin(const BNode *nodes, uint32_t begin, uint32_t end, const uint32_t *node_of, const uint32_t *order, Prims P, uint32_t n,
+                                              Bins *bins) {
+    __shared__ Bins wave_bins[4];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t v = node_of[i];
-    if (v < begin || v >= end || !node_active(nodes[v])) return;
+    const uint32_t v = i < n ? node_of[i] : 0xFFFFFFFFu;
+    const bool live = i < n && v >= begin && v < end && node_active(nodes[v]);
+    const bool uniform = wave_uniform(live, v);
+    if (!uniform && !live) return;
     const BNode &nd = nodes[v];
     const uint32_t prim = order[i];
-    Bins &b = bins[nd.bin_slot];
+    Bins &out = bins[nd.bin_slot];
+    Bins &mine = wave_bins[threadIdx.x >> 6];
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t *mine_words = reinterpret_cast<uint32_t *>(&mine);
+    constexpr uint32_t kLoWords = 3 * kBins * 3, kWords = sizeof(Bins) / 4;  // lo[...] | hi[...] | count[...]
+    if (uniform) {
+        for (uint32_t w = lane; w < kWords; w += 64) mine_words[w] = (w < kLoWords) ? 0xFFFFFFFFu : 0u;
+        __builtin_amdgcn_wave_barrier();
+    }
+    Bins &dst = uniform ? mine : out;
     for (int a = 0; a < 3; ++a) {
         const float cmin = dec(nd.cb_lo[a]), cmax = dec(nd.cb_hi[a]);
         const float extent = cmax - cmin;
@@ -207,10 +284,24 @@ __global__ void kb_bin(const BNode *nodes, uint32_t begin, uint32_t end, const u
         const float scaled = (P.centroid[a][prim] - cmin) * inv_width;
         int j = int(scaled * kBins);
         j = j < 0 ? 0 : (j > kBins - 1 ? kBins - 1 : j);
-        atomicAdd(&b.count[a][j], 1u);
+        atomicAdd(&dst.count[a][j], 1u);
         for (int c = 0; c < 3; ++c) {
-            atomicMin(&b.lo[a][j][c], enc(P.lo[c][prim]));
-            atomicMax(&b.hi[a][j][c], enc(P.hi[c][prim]));
+            atomicMin(&dst.lo[a][j][c], enc(P.lo[c][prim]));
+            atomicMax(&dst.hi[a][j][c], enc(P.hi[c][prim]));
+        }
+    }
+    if (uniform) {
+        __builtin_amdgcn_wave_barrier();
+        uint32_t *out_words = reinterpret_cast<uint32_t *>(&out);
+        for (uint32_t w = lane; w < kWords; w += 64) {
+            const uint32_t x = mine_words[w];
+            if (w < kLoWords) {
+                if (x != 0xFFFFFFFFu) atomicMin(&out_words[w], x);
+            } else if (w < 2 * kLoWords) {
+                if (x != 0u) atomicMax(&out_words[w], x);
+            } else if (x != 0u) {
+                atomicAdd(&out_words[w], x);
+            }
         }
     }
 }
@@ -235,20 +326,17 @@ struct RBox {
     }
 };
 
-// FindSplitPlane's sweep and Subdivide's cost test (bvh.cpp:72-77,167-198), one thread per node.
-__global__ void kb_split(BNode *nodes, uint32_t begin, uint32_t end, const Bins *bins) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (begin + k >= end) return;
-    BNode &n = nodes[begin + k];
-    if (!node_active(n)) return;
-    const Bins &b = bins[n.bin_slot];
+// FindSplitPlane's sweep and Subdivide's cost test (bvh.cpp:72-77,167-198) for one node, given its
+// bins and centroid bounds (enc() coded) and its own box.  False: the node stays a leaf.
+PTB_D bool find_split(const Bins &b, const uint32_t *cb_lo, const uint32_t *cb_hi, uint32_t count, const float *node_lo, const float *node_hi, int &axis,
+                      float &pos) {
     float best_cost = FLT_MAX, best_pos = 0.0f;
     int best_axis = -1;
     bool empty = false;
-    for (int a = 0; a < 3; ++a) empty = empty || (dec(n.cb_lo[a]) > dec(n.cb_hi[a]));
+    for (int a = 0; a < 3; ++a) empty = empty || (dec(cb_lo[a]) > dec(cb_hi[a]));
     if (!empty) {
         for (int a = 0; a < 3; ++a) {
-            const float cmin = dec(n.cb_lo[a]), cmax = dec(n.cb_hi[a]);
+            const float cmin = dec(cb_lo[a]), cmax = dec(cb_hi[a]);
             const float extent = cmax - cmin;
             if (extent <= 0.0f) continue;
             float left_area[kBins - 1], right_area[kBins - 1];
@@ -261,7 +349,7 @@ __global__ void kb_split(BNode *nodes, uint32_t begin, uint32_t end, const Bins 
                 float l[3], h[3];
                 lsum += b.count[a][i];
                 left_count[i] = lsum;
-                for (int c = 0; c < 3; ++c) {  // an untouched bin decodes to the empty box
+                for (int c = 0; c < 3; ++c) {  // an untouched bin is the empty box
                     l[c] = b.count[a][i] ? dec(b.lo[a][i][c]) : FLT_MAX;
                     h[c] = b.count[a][i] ? dec(b.hi[a][i][c]) : -FLT_MAX;
                 }
@@ -289,13 +377,26 @@ __global__ void kb_split(BNode *nodes, uint32_t begin, uint32_t end, const Bins 
     }
     RBox nb;
     for (int a = 0; a < 3; ++a) {
-        nb.lo[a] = n.lo[a];
-        nb.hi[a] = n.hi[a];
+        nb.lo[a] = node_lo[a];
+        nb.hi[a] = node_hi[a];
     }
-    const float parent_cost = n.count * nb.area();
-    if (best_axis < 0 || best_cost >= parent_cost) return;
-    n.axis = best_axis;
-    n.pos = best_pos;
+    const float parent_cost = count * nb.area();
+    if (best_axis < 0 || best_cost >= parent_cost) return false;
+    axis = best_axis;
+    pos = best_pos;
+    return true;
+}
+
+__global__ void kb_split(BNode *nodes, uint32_t begin, uint32_t end, const Bins *bins) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (begin + k >= end) return;
+    BNode &n = nodes[begin + k];
+    if (!node_active(n)) return;
+    int axis;
+    float pos;
+    if (!find_split(bins[n.bin_slot], n.cb_lo, n.cb_hi, n.count, n.lo, n.hi, axis, pos)) return;
+    n.axis = axis;
+    n.pos = pos;
 }
 
 __global__ void kb_flags(const BNode *nodes, uint32_t begin, uint32_t end, const uint32_t *node_of, const uint32_t *order, Prims P, uint32_t n, uint32_t *flag) {
@@ -392,7 +493,7 @@ __global__ void kb_rank_tables(const BNode *nodes, uint32_t begin, uint32_t end,
 //   r = 0), every other one moves one slot towards the front.
 // This kernel finds K and K' per node, allocates the children and names the entries' new owner.
 __global__ void kb_pairs(BNode *nodes, uint32_t begin, uint32_t end, const uint32_t *scan, const uint32_t *pfront, const uint32_t *qback, uint32_t *node_count,
-                         unsigned long long *keys) {
+                         unsigned long long *keys, uint32_t *small_list, uint32_t *small_count) {
     const uint32_t v = begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= end) return;
     BNode &n = nodes[v];
@@ -418,10 +519,14 @@ __global__ void kb_pairs(BNode *nodes, uint32_t begin, uint32_t end, const uint3
     c.axis = -1;
     c.first = first;
     c.count = n_left;
+    c.small = n_left <= kSmall;
     nodes[left] = c;
+    if (c.small) small_list[atomicAdd(small_count, 1u)] = left;
     c.first = first + n_left;
     c.count = n_right;
+    c.small = n_right <= kSmall;
     nodes[left + 1] = c;
+    if (c.small) small_list[atomicAdd(small_count, 1u)] = left + 1;
     for (uint32_t s = 0; s < 2; ++s)
         for (int k = 0; k < 3; ++k) {
             keys[6 * size_t(left + s) + k] = ~0ull;
@@ -456,18 +561,196 @@ __global__ void kb_scatter(const BNode *nodes, uint32_t begin, uint32_t end, con
     node_of_out[dest] = nd.left ? (dest < first + n_left ? nd.left : nd.left + 1) : v;
 }
 
+// ------------------------------------------------------------------ small subtrees, one wave each
+struct SmallLds {
+    uint32_t prim[kSmall];                                  // triangle of each slot
+    float c[3][kSmall], lo[3][kSmall], hi[3][kSmall];       // centroid and box of each slot
+    uint16_t perm[kSmall];                                  // entry (position inside the subtree) -> slot
+    uint16_t nfirst[2 * kSmall], ncount[2 * kSmall], nleft[2 * kSmall];  // the subtree's nodes, numbered as the reference
+    float nlo[2 * kSmall][3], nhi[2 * kSmall][3];                        // numbers them: children allocated on subdivision
+    uint16_t stack[2 * kSmall];
+    Bins bins;
+    unsigned long long keys[12];
+    int split;
+    uint32_t left_count;
+};
+
+// Subdivide (bvh.cpp:67-113) over the whole subtree of one node, depth first.  Reductions (centroid
+// bounds, bins, child boxes) run across the lanes; the plane sweep and the two-cursor partition
+// are the reference's sequential code on lane 0.
+__global__ __launch_bounds__(64) void kb_small_subtrees(BNode *nodes, const uint32_t *small_list, uint32_t small_count, uint32_t *order, Prims P,
+                                                        uint32_t *node_count) {
+    __shared__ SmallLds L;
+    if (blockIdx.x >= small_count) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t root = small_list[blockIdx.x];
+    const uint32_t first = nodes[root].first, cnt = nodes[root].count, blas = nodes[root].blas;
+    for (uint32_t e = lane; e < cnt; e += 64) {
+        const uint32_t prim = order[first + e];
+        L.prim[e] = prim;
+        L.perm[e] = uint16_t(e);
+        for (int a = 0; a < 3; ++a) {
+            L.c[a][e] = P.centroid[a][prim];
+            L.lo[a][e] = P.lo[a][prim];
+            L.hi[a][e] = P.hi[a][prim];
+        }
+    }
+    if (lane == 0) {
+        L.nfirst[0] = 0;
+        L.ncount[0] = uint16_t(cnt);
+        L.nleft[0] = 0;
+        for (int a = 0; a < 3; ++a) {
+            L.nlo[0][a] = nodes[root].lo[a];
+            L.nhi[0][a] = nodes[root].hi[a];
+        }
+        L.stack[0] = 0;
+    }
+    __syncthreads();
+    uint32_t sp = 1, next_local = 1, splits = 0;  // the same in every lane
+    uint32_t *bin_words = reinterpret_cast<uint32_t *>(&L.bins);
+    constexpr uint32_t kLoWords = 3 * kBins * 3, kWords = sizeof(Bins) / 4;
+    while (sp > 0) {
+        const uint32_t l = L.stack[--sp];
+        const uint32_t f = L.nfirst[l], c = L.ncount[l];
+        if (c <= 2) continue;  // bvh.cpp:69
+        uint32_t cb_lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, cb_hi[3] = {0u, 0u, 0u};
+        for (uint32_t e = f + lane; e < f + c; e += 64) {
+            const uint32_t slot = L.perm[e];
+            for (int a = 0; a < 3; ++a) {
+                const uint32_t x = enc(L.c[a][slot]);
+                cb_lo[a] = x < cb_lo[a] ? x : cb_lo[a];
+                cb_hi[a] = x > cb_hi[a] ? x : cb_hi[a];
+            }
+        }
+        for (int a = 0; a < 3; ++a) {
+            cb_lo[a] = wave_min(cb_lo[a]);
+            cb_hi[a] = wave_max(cb_hi[a]);
+        }
+        for (uint32_t w = lane; w < kWords; w += 64) bin_words[w] = (w < kLoWords) ? 0xFFFFFFFFu : 0u;
+        __syncthreads();
+        for (uint32_t e = f + lane; e < f + c; e += 64) {
+            const uint32_t slot = L.perm[e];
+            for (int a = 0; a < 3; ++a) {
+                const float cmin = dec(cb_lo[a]), cmax = dec(cb_hi[a]);
+                const float extent = cmax - cmin;
+                if (extent <= 0.0f) continue;
+                const float inv_width = 1.0f / fmax_ref(extent, 1e-30f);
+                const float scaled = (L.c[a][slot] - cmin) * inv_width;
+                int j = int(scaled * kBins);
+                j = j < 0 ? 0 : (j > kBins - 1 ? kBins - 1 : j);
+                atomicAdd(&L.bins.count[a][j], 1u);
+                for (int k = 0; k < 3; ++k) {
+                    atomicMin(&L.bins.lo[a][j][k], enc(L.lo[k][slot]));
+                    atomicMax(&L.bins.hi[a][j][k], enc(L.hi[k][slot]));
+                }
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {
+            int axis = 0;
+            float pos = 0.0f;
+            const bool split = find_split(L.bins, cb_lo, cb_hi, c, L.nlo[l], L.nhi[l], axis, pos);
+            L.split = split ? 1 : 0;
+            if (split) {  // bvh.cpp:80-86
+                uint32_t i = f, j = f + c - 1;
+                while (i <= j) {
+                    if (L.c[axis][L.perm[i]] < pos) {
+                        ++i;
+                    } else {
+                        const uint16_t t = L.perm[i];
+                        L.perm[i] = L.perm[j];
+                        L.perm[j] = t;
+                        if (j == 0) break;  // all entries right of the plane in a subtree that starts at 0
+                        --j;
+                    }
+                }
+                L.left_count = i - f;
+            }
+        }
+        __syncthreads();
+        if (!L.split) continue;
+        const uint32_t lc = L.left_count;
+        if (lc == 0 || lc == c) continue;  // bvh.cpp:88-89
+        const uint32_t ll = next_local;
+        next_local += 2;
+        ++splits;
+        if (lane < 12) L.keys[lane] = (lane % 6 < 3) ? ~0ull : 0ull;
+        __syncthreads();
+        for (uint32_t e = f + lane; e < f + c; e += 64) {  // UpdateNodeBounds of both children (bvh.cpp:53-65)
+            const uint32_t slot = L.perm[e];
+            const uint32_t child = (e < f + lc) ? 0u : 1u;
+            for (int a = 0; a < 3; ++a) {
+                atomicMin(&L.keys[child * 6 + a], ((unsigned long long)enc_eq(L.lo[a][slot]) << 32) | e);
+                atomicMax(&L.keys[child * 6 + 3 + a], ((unsigned long long)enc_eq(L.hi[a][slot]) << 32) | (0xFFFFFFFFu - e));
+            }
+        }
+        __syncthreads();
+        if (lane < 12) {
+            const uint32_t child = lane / 6, k = lane % 6;
+            if (k < 3) L.nlo[ll + child][k] = L.lo[k][L.perm[uint32_t(L.keys[lane])]];
+            else L.nhi[ll + child][k - 3] = L.hi[k - 3][L.perm[0xFFFFFFFFu - uint32_t(L.keys[lane])]];
+        }
+        if (lane == 0) {
+            L.nfirst[ll] = uint16_t(f);
+            L.ncount[ll] = uint16_t(lc);
+            L.nleft[ll] = 0;
+            L.nfirst[ll + 1] = uint16_t(f + lc);
+            L.ncount[ll + 1] = uint16_t(c - lc);
+            L.nleft[ll + 1] = 0;
+            L.nleft[l] = uint16_t(ll);
+            L.stack[sp] = uint16_t(ll + 1);  // the left child is subdivided first (bvh.cpp:111-112)
+            L.stack[sp + 1] = uint16_t(ll);
+        }
+        sp += 2;
+        __syncthreads();
+    }
+    uint32_t base = 0;
+    if (lane == 0 && next_local > 1) base = atomicAdd(node_count, next_local - 1);
+    base = __builtin_amdgcn_readfirstlane(base);
+    for (uint32_t e = lane; e < cnt; e += 64) order[first + e] = L.prim[L.perm[e]];
+    for (uint32_t l = 1 + lane; l < next_local; l += 64) {
+        BNode o = {};
+        o.first = first + L.nfirst[l];
+        o.count = L.ncount[l];
+        o.left = L.nleft[l] ? base + L.nleft[l] - 1 : 0u;
+        o.blas = blas;
+        for (int a = 0; a < 3; ++a) {
+            o.lo[a] = L.nlo[l][a];
+            o.hi[a] = L.nhi[l][a];
+        }
+        o.axis = -1;
+        o.owner = root;
+        o.local = l;
+        nodes[base + l - 1] = o;
+    }
+    if (lane == 0) {
+        nodes[root].left = L.nleft[0] ? base + L.nleft[0] - 1 : 0u;
+        nodes[root].internal = splits;
+    }
+}
+
+// Final index of the nodes inside single-wave subtrees: the subtree's k-th subdivided node is the
+// mesh's (rank(root) + k)-th, so local number l (>= 1) becomes 2 * rank(root) + l.
+__global__ void kb_small_indices(BNode *nodes, uint32_t begin, uint32_t end) {
+    const uint32_t v = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= end) return;
+    BNode &n = nodes[v];
+    n.index = 2u * nodes[n.owner].rank + n.local;
+}
+
 // ------------------------------------------------------------------ renumbering and output
 __global__ void kb_subtree_sizes(BNode *nodes, uint32_t begin, uint32_t end) {
     const uint32_t v = begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= end) return;
     BNode &n = nodes[v];
+    if (n.small) return;  // counted by the wave that built the subtree
     n.internal = n.left ? 1u + nodes[n.left].internal + nodes[n.left + 1].internal : 0u;
 }
 __global__ void kb_preorder(BNode *nodes, uint32_t begin, uint32_t end) {
     const uint32_t v = begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= end) return;
     const BNode &n = nodes[v];
-    if (!n.left) return;
+    if (!n.left || n.small) return;
     BNode &l = nodes[n.left], &r = nodes[n.left + 1];
     l.index = 1u + 2u * n.rank;
     r.index = 2u + 2u * n.rank;
@@ -758,9 +1041,11 @@ inline int BuildOnDevice(hipStream_t stream, const float *positions, uint32_t ve
         PTB_TRY(mem.get(&P.centroid[a], n));
     }
     PTB_TRY(mem.get(&P.blas, n));
-    const size_t max_nodes = 2 * size_t(n) + mesh_count;
-    const size_t max_active = size_t(n) / 3 + mesh_count;
-    uint32_t *order[2], *node_of[2], *flag, *scan, *pfront, *qback, *tile_sums, *counters;
+    // nodes made by the level passes (every one holds a triangle, every split makes two) and, behind
+    // them, the nodes made inside single-wave subtrees (fewer than two per triangle)
+    const size_t max_level_nodes = 2 * size_t(n) + mesh_count, max_nodes = max_level_nodes + 2 * size_t(n);
+    const size_t max_active = size_t(n) / kSmall + mesh_count;
+    uint32_t *order[2], *node_of[2], *flag, *scan, *pfront, *qback, *tile_sums, *counters, *small_list;
     BNode *nodes;
     Bins *bins;
     unsigned long long *keys;
@@ -773,10 +1058,12 @@ inline int BuildOnDevice(hipStream_t stream, const float *positions, uint32_t ve
     PTB_TRY(mem.get(&pfront, n));
     PTB_TRY(mem.get(&qback, n));
     PTB_TRY(mem.get(&tile_sums, 8192));
-    PTB_TRY(mem.get(&counters, 4));  // [0] node count, [1] scan total, [2] TLAS status, [3] bin slots of the pass
+    PTB_TRY(mem.get(&counters, 8));  // [0] node count, [1] scan total, [2] TLAS status, [3] bin slots of the pass, [4] small subtrees
+    PTB_TRY(mem.get(&small_list, size_t(n) + mesh_count));
     PTB_TRY(mem.get(&nodes, max_nodes));
     PTB_TRY(mem.get(&bins, max_active));
-    PTB_TRY(mem.get(&keys, max_nodes * 6));
+    PTB_TRY(mem.get(&keys, max_level_nodes * 6));
+    PTB_TRY(hipMemsetAsync(counters, 0, 8 * 4, stream));
 
     hipEvent_t ev[3];
     for (hipEvent_t &e : ev) PTB_TRY(hipEventCreate(&e));
@@ -789,7 +1076,7 @@ inline int BuildOnDevice(hipStream_t stream, const float *positions, uint32_t ve
     PTB_TRY(hipEventRecord(ev[0], stream));
 
     hipLaunchKernelGGL(kb_prims, dim3(Blocks(n)), dim3(256), 0, stream, d_positions, d_indices, d_meshes, mesh_count, P, n, order[0], node_of[0]);
-    hipLaunchKernelGGL(kb_roots, dim3(Blocks(mesh_count)), dim3(256), 0, stream, nodes, d_meshes, mesh_count, keys);
+    hipLaunchKernelGGL(kb_roots, dim3(Blocks(mesh_count)), dim3(256), 0, stream, nodes, d_meshes, mesh_count, keys, small_list, counters + 4);
     hipLaunchKernelGGL(kb_bounds_keys, dim3(Blocks(n)), dim3(256), 0, stream, nodes, 0u, mesh_count, node_of[0], order[0], P, n, keys);
     hipLaunchKernelGGL(kb_bounds_decode, dim3(Blocks(mesh_count)), dim3(256), 0, stream, nodes, 0u, mesh_count, keys, order[0], P);
     uint32_t node_count = mesh_count;
@@ -812,13 +1099,13 @@ inline int BuildOnDevice(hipStream_t stream, const float *positions, uint32_t ve
         hipLaunchKernelGGL(kb_scan_sums, dim3(1), dim3(1024), 0, stream, tile_sums, tiles, counters + 1);
         hipLaunchKernelGGL(kb_scan_add, dim3(Blocks(n)), dim3(256), 0, stream, scan, n, tile_sums, counters + 1);
         hipLaunchKernelGGL(kb_rank_tables, dim3(Blocks(n)), dim3(256), 0, stream, nodes, begin, end, node_of[cur], flag, scan, n, pfront, qback);
-        hipLaunchKernelGGL(kb_pairs, dim3(Blocks(width, 64)), dim3(64), 0, stream, nodes, begin, end, scan, pfront, qback, counters, keys);
+        hipLaunchKernelGGL(kb_pairs, dim3(Blocks(width, 64)), dim3(64), 0, stream, nodes, begin, end, scan, pfront, qback, counters, keys, small_list, counters + 4);
         hipLaunchKernelGGL(kb_scatter, dim3(Blocks(n)), dim3(256), 0, stream, nodes, begin, end, node_of[cur], order[cur], flag, scan, pfront, qback, n,
                            order[cur ^ 1], node_of[cur ^ 1]);
         cur ^= 1;
         PTB_TRY(hipMemcpyAsync(&node_count, counters, 4, hipMemcpyDeviceToHost, stream));
         PTB_TRY(hipStreamSynchronize(stream));
-        if (node_count > max_nodes) {
+        if (node_count > max_level_nodes) {
             err = "internal: node storage exceeded";
             return PT_ERR_DEVICE;
         }
@@ -831,11 +1118,28 @@ inline int BuildOnDevice(hipStream_t stream, const float *positions, uint32_t ve
     }
     out.levels = uint32_t(levels.size());
 
+    // ---- subtrees of kSmall triangles or fewer, one wave each
+    const uint32_t level_nodes = node_count;
+    uint32_t small_count = 0;
+    PTB_TRY(hipMemcpyAsync(&small_count, counters + 4, 4, hipMemcpyDeviceToHost, stream));
+    PTB_TRY(hipStreamSynchronize(stream));
+    if (small_count > 0) {
+        hipLaunchKernelGGL(kb_small_subtrees, dim3(small_count), dim3(64), 0, stream, nodes, small_list, small_count, order[cur], P, counters);
+        PTB_TRY(hipMemcpyAsync(&node_count, counters, 4, hipMemcpyDeviceToHost, stream));
+        PTB_TRY(hipStreamSynchronize(stream));
+        if (node_count > max_nodes) {
+            err = "internal: node storage exceeded";
+            return PT_ERR_DEVICE;
+        }
+    }
+
     // ---- renumber: subtree sizes bottom-up, preorder ranks top-down
     for (size_t l = levels.size(); l-- > 0;)
         hipLaunchKernelGGL(kb_subtree_sizes, dim3(Blocks(levels[l].second - levels[l].first)), dim3(256), 0, stream, nodes, levels[l].first, levels[l].second);
     for (size_t l = 0; l < levels.size(); ++l)
         hipLaunchKernelGGL(kb_preorder, dim3(Blocks(levels[l].second - levels[l].first)), dim3(256), 0, stream, nodes, levels[l].first, levels[l].second);
+    if (node_count > level_nodes)
+        hipLaunchKernelGGL(kb_small_indices, dim3(Blocks(node_count - level_nodes)), dim3(256), 0, stream, nodes, level_nodes, node_count);
     std::vector<BNode> roots(mesh_count);
     PTB_TRY(hipMemcpyAsync(roots.data(), nodes, size_t(mesh_count) * sizeof(BNode), hipMemcpyDeviceToHost, stream));
     PTB_TRY(hipStreamSynchronize(stream));
