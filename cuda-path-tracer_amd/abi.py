@@ -143,7 +143,7 @@ PTH_SYMBOLS = [
     "pth_alias_build", "pth_camera_make", "pth_bvh_build", "pth_bvh_sizes", "pth_bvh_get", "pth_bvh_free",
     "pth_scene_create", "pth_scene_destroy", "pth_scene_set_integrator", "pth_scene_set_camera", "pth_scene_add_mesh",
     "pth_scene_add_material", "pth_scene_add_texture1", "pth_scene_add_texture3", "pth_scene_add_image",
-    "pth_scene_new_blas_index", "pth_scene_add_instance", "pth_scene_finalize", "pth_scene_get_desc",
+    "pth_scene_new_blas_index", "pth_scene_add_instance", "pth_scene_finalize", "pth_scene_finalize_device", "pth_scene_get_desc",
     "pth_scene_update_device", "pth_integrator_create", "pth_integrator_destroy", "pth_integrator_init",
     "pth_integrator_resize", "pth_integrator_reset", "pth_integrator_render", "pth_debug_render", "pth_save_png", "pth_save_hdr"]
 
@@ -235,6 +235,7 @@ def load_library() -> C.CDLL:
         "pth_scene_new_blas_index": (i32, [vp, C.POINTER(i32)]),
         "pth_scene_add_instance": (i32, [vp, u32, u32, u32, i32, fp, i32, C.POINTER(i32)]),
         "pth_scene_finalize": (i32, [vp]),
+        "pth_scene_finalize_device": (i32, [vp, vp]),
         "pth_scene_get_desc": (i32, [vp, C.POINTER(SceneDesc)]),
         "pth_scene_update_device": (i32, [vp, vp]),
         "pth_integrator_create": (i32, [vp, C.POINTER(vp)]),

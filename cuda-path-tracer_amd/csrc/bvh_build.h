@@ -176,27 +176,60 @@ PTB_D unsigned long long wave_max64(unsigned long long x) {
     return x;
 }
 
+constexpr uint32_t kAggBlock = 1024, kAggWaves = kAggBlock / 64;
+
+// True when every wave of the block lies inside the same node (s_v = per-wave node, or
+// 0xFFFFFFFF for a wave that does not).  Contains a barrier: all threads must call it.
+PTB_D bool block_uniform(uint32_t *s_v, bool wave_is_uniform, uint32_t v) {
+    if ((threadIdx.x & 63) == 0) s_v[threadIdx.x >> 6] = wave_is_uniform ? v : 0xFFFFFFFFu;
+    __syncthreads();
+    bool same = s_v[0] != 0xFFFFFFFFu;
+    for (uint32_t w = 1; w < kAggWaves; ++w) same = same && s_v[w] == s_v[0];
+    return same;
+}
+
 // Box of the nodes [begin, end): union of the boxes of their entries, as (value, position) keys.
-// A node's entries are contiguous, so most waves lie inside one node and send one atomic per
-// value instead of 64 to the same address.
-__global__ void kb_bounds_keys(const BNode *nodes, uint32_t begin, uint32_t end, const uint32_t *node_of, const uint32_t *order, Prims P, uint32_t n,
-                               unsigned long long *keys) {
+// A node's entries are contiguous, so most waves (and, for large nodes, whole blocks) lie inside
+// one node: they reduce across lanes and through LDS first, and send one atomic per value where
+// the lanes alone would send a thousand to the same address (those serialise at ~12 ns each).
+__global__ __launch_bounds__(kAggBlock) void kb_bounds_keys(const BNode *nodes, uint32_t begin, uint32_t end, const uint32_t *node_of, const uint32_t *order,
+                                                            Prims P, uint32_t n, unsigned long long *keys) {
+    __shared__ uint32_t s_v[kAggWaves];
+    __shared__ unsigned long long s_k[kAggWaves][6];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t v = i < n ? node_of[i] : 0xFFFFFFFFu;
     const bool live = i < n && v >= begin && v < end;
     const uint32_t prim = live ? order[i] : 0u;
     const bool uniform = wave_uniform(live, v);
-    if (!uniform && !live) return;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long k[6];
     for (int a = 0; a < 3; ++a) {
-        unsigned long long klo = ((unsigned long long)enc_eq(P.lo[a][prim]) << 32) | i;
-        unsigned long long khi = ((unsigned long long)enc_eq(P.hi[a][prim]) << 32) | (0xFFFFFFFFu - i);
+        k[a] = ((unsigned long long)enc_eq(P.lo[a][prim]) << 32) | i;
+        k[3 + a] = ((unsigned long long)enc_eq(P.hi[a][prim]) << 32) | (0xFFFFFFFFu - i);
         if (uniform) {
-            klo = wave_min64(klo);
-            khi = wave_max64(khi);
-            if ((threadIdx.x & 63) != 0) continue;
+            k[a] = wave_min64(k[a]);
+            k[3 + a] = wave_max64(k[3 + a]);
         }
-        atomicMin(&keys[6 * size_t(v) + a], klo);
-        atomicMax(&keys[6 * size_t(v) + 3 + a], khi);
+    }
+    if (uniform && lane == 0)
+        for (int q = 0; q < 6; ++q) s_k[wave][q] = k[q];
+    const bool whole_block = block_uniform(s_v, uniform, v);
+    if (whole_block) {
+        if (threadIdx.x < 6) {
+            unsigned long long r = s_k[0][threadIdx.x];
+            for (uint32_t w = 1; w < kAggWaves; ++w) {
+                const unsigned long long o = s_k[w][threadIdx.x];
+                r = (threadIdx.x < 3) ? (o < r ? o : r) : (o > r ? o : r);
+            }
+            if (threadIdx.x < 3) atomicMin(&keys[6 * size_t(s_v[0]) + threadIdx.x], r);
+            else atomicMax(&keys[6 * size_t(s_v[0]) + threadIdx.x], r);
+        }
+        return;
+    }
+    if (!live || (uniform && lane != 0)) return;
+    for (int a = 0; a < 3; ++a) {
+        atomicMin(&keys[6 * size_t(v) + a], k[a]);
+        atomicMax(&keys[6 * size_t(v) + 3 + a], k[3 + a]);
     }
 }
 __global__ void kb_bounds_decode(BNode *nodes, uint32_t begin, uint32_t end, const unsigned long long *keys, const uint32_t *order, Prims P) {
@@ -235,73 +268,103 @@ __global__ void kb_level_init(BNode *nodes, uint32_t begin, uint32_t end, Bins *
         }
 }
 
-__global__ void kb_centroid_bounds(BNode *nodes, uint32_t begin, uint32_t end, const uint32_t *node_of, const uint32_t *order, Prims P, uint32_t n) {
+__global__ __launch_bounds__(kAggBlock) void kb_centroid_bounds(BNode *nodes, uint32_t begin, uint32_t end, const uint32_t *node_of, const uint32_t *order,
+                                                                Prims P, uint32_t n) {
+    __shared__ uint32_t s_v[kAggWaves];
+    __shared__ uint32_t s_e[kAggWaves][6];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t v = i < n ? node_of[i] : 0xFFFFFFFFu;
     const bool live = i < n && v >= begin && v < end && node_active(nodes[v]);
     const uint32_t prim = live ? order[i] : 0u;
     const bool uniform = wave_uniform(live, v);
-    if (!uniform && !live) return;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t e[6];
     for (int a = 0; a < 3; ++a) {
-        uint32_t lo = enc(P.centroid[a][prim]), hi = lo;
+        e[a] = e[3 + a] = enc(P.centroid[a][prim]);
         if (uniform) {
-            lo = wave_min(lo);
-            hi = wave_max(hi);
-            if ((threadIdx.x & 63) != 0) continue;
+            e[a] = wave_min(e[a]);
+            e[3 + a] = wave_max(e[3 + a]);
         }
-        atomicMin(&nodes[v].cb_lo[a], lo);
-        atomicMax(&nodes[v].cb_hi[a], hi);
+    }
+    if (uniform && lane == 0)
+        for (int q = 0; q < 6; ++q) s_e[wave][q] = e[q];
+    const bool whole_block = block_uniform(s_v, uniform, v);
+    if (whole_block) {
+        if (threadIdx.x < 6) {
+            uint32_t r = s_e[0][threadIdx.x];
+            for (uint32_t w = 1; w < kAggWaves; ++w) {
+                const uint32_t o = s_e[w][threadIdx.x];
+                r = (threadIdx.x < 3) ? (o < r ? o : r) : (o > r ? o : r);
+            }
+            if (threadIdx.x < 3) atomicMin(&nodes[s_v[0]].cb_lo[threadIdx.x], r);
+            else atomicMax(&nodes[s_v[0]].cb_hi[threadIdx.x - 3], r);
+        }
+        return;
+    }
+    if (!live || (uniform && lane != 0)) return;
+    for (int a = 0; a < 3; ++a) {
+        atomicMin(&nodes[v].cb_lo[a], e[a]);
+        atomicMax(&nodes[v].cb_hi[a], e[3 + a]);
     }
 }
 
 // bvh.cpp:151-165: bin index of a centroid on every axis whose centroid extent is positive.
-// A wave that lies inside one node bins into LDS first and sends each touched bin once.
-__global__ __launch_bounds__(256) void kb_bin(const BNode *nodes, uint32_t begin, uint32_t end, const uint32_t *node_of, const uint32_t *order, Prims P, uint32_t n,
-                                              Bins *bins) {
-    __shared__ Bins wave_bins[4];
+// A block (or, failing that, a wave) that lies inside one node bins into LDS first and sends
+// each touched bin once.
+__global__ __launch_bounds__(kAggBlock) void kb_bin(const BNode *nodes, uint32_t begin, uint32_t end, const uint32_t *node_of, const uint32_t *order, Prims P,
+                                                    uint32_t n, Bins *bins) {
+    __shared__ uint32_t s_v[kAggWaves];
+    __shared__ Bins s_bins[kAggWaves];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t v = i < n ? node_of[i] : 0xFFFFFFFFu;
     const bool live = i < n && v >= begin && v < end && node_active(nodes[v]);
     const bool uniform = wave_uniform(live, v);
-    if (!uniform && !live) return;
-    const BNode &nd = nodes[v];
-    const uint32_t prim = order[i];
-    Bins &out = bins[nd.bin_slot];
-    Bins &mine = wave_bins[threadIdx.x >> 6];
-    const uint32_t lane = threadIdx.x & 63;
-    uint32_t *mine_words = reinterpret_cast<uint32_t *>(&mine);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr uint32_t kLoWords = 3 * kBins * 3, kWords = sizeof(Bins) / 4;  // lo[...] | hi[...] | count[...]
-    if (uniform) {
-        for (uint32_t w = lane; w < kWords; w += 64) mine_words[w] = (w < kLoWords) ? 0xFFFFFFFFu : 0u;
-        __builtin_amdgcn_wave_barrier();
-    }
-    Bins &dst = uniform ? mine : out;
-    for (int a = 0; a < 3; ++a) {
-        const float cmin = dec(nd.cb_lo[a]), cmax = dec(nd.cb_hi[a]);
-        const float extent = cmax - cmin;
-        if (extent <= 0.0f) continue;
-        const float inv_width = 1.0f / fmax_ref(extent, 1e-30f);
-        const float scaled = (P.centroid[a][prim] - cmin) * inv_width;
-        int j = int(scaled * kBins);
-        j = j < 0 ? 0 : (j > kBins - 1 ? kBins - 1 : j);
-        atomicAdd(&dst.count[a][j], 1u);
-        for (int c = 0; c < 3; ++c) {
-            atomicMin(&dst.lo[a][j][c], enc(P.lo[c][prim]));
-            atomicMax(&dst.hi[a][j][c], enc(P.hi[c][prim]));
+    uint32_t *wave_words = reinterpret_cast<uint32_t *>(&s_bins[wave]);
+    for (uint32_t w = lane; w < kWords; w += 64) wave_words[w] = (w < kLoWords) ? 0xFFFFFFFFu : 0u;
+    const bool whole_block = block_uniform(s_v, uniform, v);  // (barrier: the LDS bins are initialised)
+    if (live) {
+        const BNode &nd = nodes[v];
+        const uint32_t prim = order[i];
+        Bins &dst = whole_block ? s_bins[0] : (uniform ? s_bins[wave] : bins[nd.bin_slot]);
+        for (int a = 0; a < 3; ++a) {
+            const float cmin = dec(nd.cb_lo[a]), cmax = dec(nd.cb_hi[a]);
+            const float extent = cmax - cmin;
+            if (extent <= 0.0f) continue;
+            const float inv_width = 1.0f / fmax_ref(extent, 1e-30f);
+            const float scaled = (P.centroid[a][prim] - cmin) * inv_width;
+            int j = int(scaled * kBins);
+            j = j < 0 ? 0 : (j > kBins - 1 ? kBins - 1 : j);
+            atomicAdd(&dst.count[a][j], 1u);
+            for (int c = 0; c < 3; ++c) {
+                atomicMin(&dst.lo[a][j][c], enc(P.lo[c][prim]));
+                atomicMax(&dst.hi[a][j][c], enc(P.hi[c][prim]));
+            }
         }
     }
-    if (uniform) {
-        __builtin_amdgcn_wave_barrier();
-        uint32_t *out_words = reinterpret_cast<uint32_t *>(&out);
-        for (uint32_t w = lane; w < kWords; w += 64) {
-            const uint32_t x = mine_words[w];
-            if (w < kLoWords) {
-                if (x != 0xFFFFFFFFu) atomicMin(&out_words[w], x);
-            } else if (w < 2 * kLoWords) {
-                if (x != 0u) atomicMax(&out_words[w], x);
-            } else if (x != 0u) {
-                atomicAdd(&out_words[w], x);
-            }
+    __syncthreads();
+    const uint32_t *src = nullptr;
+    uint32_t w0 = 0, step = 0;
+    if (whole_block) {
+        src = reinterpret_cast<const uint32_t *>(&s_bins[0]);
+        w0 = threadIdx.x;
+        step = kAggBlock;
+    } else if (uniform) {
+        src = wave_words;
+        w0 = lane;
+        step = 64;
+    }
+    if (!src) return;
+    uint32_t *out_words = reinterpret_cast<uint32_t *>(&bins[nodes[v].bin_slot]);
+    for (uint32_t w = w0; w < kWords; w += step) {
+        const uint32_t x = src[w];
+        if (w < kLoWords) {
+            if (x != 0xFFFFFFFFu) atomicMin(&out_words[w], x);
+        } else if (w < 2 * kLoWords) {
+            if (x != 0u) atomicMax(&out_words[w], x);
+        } else if (x != 0u) {
+            atomicAdd(&out_words[w], x);
         }
     }
 }
@@ -566,18 +629,19 @@ struct SmallLds {
     uint32_t prim[kSmall];                                  // triangle of each slot
     float c[3][kSmall], lo[3][kSmall], hi[3][kSmall];       // centroid and box of each slot
     uint16_t perm[kSmall];                                  // entry (position inside the subtree) -> slot
+    uint16_t perm_next[kSmall], pfront[kSmall], qback[kSmall];  // partition scratch (see kb_pairs)
     uint16_t nfirst[2 * kSmall], ncount[2 * kSmall], nleft[2 * kSmall];  // the subtree's nodes, numbered as the reference
     float nlo[2 * kSmall][3], nhi[2 * kSmall][3];                        // numbers them: children allocated on subdivision
     uint16_t stack[2 * kSmall];
     Bins bins;
     unsigned long long keys[12];
-    int split;
-    uint32_t left_count;
 };
 
-// Subdivide (bvh.cpp:67-113) over the whole subtree of one node, depth first.  Reductions (centroid
-// bounds, bins, child boxes) run across the lanes; the plane sweep and the two-cursor partition
-// are the reference's sequential code on lane 0.
+// Subdivide (bvh.cpp:67-113) over the whole subtree of one node, depth first, by one wave.
+// Reductions (centroid bounds, bins, child boxes) run across the lanes; the 21 candidate planes
+// are costed by 21 lanes (each unions its bins in the sweep's order) and the cheapest with the
+// lowest number wins, which is what "first strictly smaller" picks; the partition uses the same
+// closed form as the level passes, with ballots for the ranks.
 __global__ __launch_bounds__(64) void kb_small_subtrees(BNode *nodes, const uint32_t *small_list, uint32_t small_count, uint32_t *order, Prims P,
                                                         uint32_t *node_count) {
     __shared__ SmallLds L;
@@ -646,30 +710,113 @@ __global__ __launch_bounds__(64) void kb_small_subtrees(BNode *nodes, const uint
             }
         }
         __syncthreads();
-        if (lane == 0) {
-            int axis = 0;
-            float pos = 0.0f;
-            const bool split = find_split(L.bins, cb_lo, cb_hi, c, L.nlo[l], L.nhi[l], axis, pos);
-            L.split = split ? 1 : 0;
-            if (split) {  // bvh.cpp:80-86
-                uint32_t i = f, j = f + c - 1;
-                while (i <= j) {
-                    if (L.c[axis][L.perm[i]] < pos) {
-                        ++i;
-                    } else {
-                        const uint16_t t = L.perm[i];
-                        L.perm[i] = L.perm[j];
-                        L.perm[j] = t;
-                        if (j == 0) break;  // all entries right of the plane in a subtree that starts at 0
-                        --j;
+        // ---- plane choice (bvh.cpp:167-198, :72-77)
+        float cost = FLT_MAX, plane = 0.0f;
+        bool candidate = false;
+        if (lane < 3 * (kBins - 1)) {
+            const int a = int(lane) / (kBins - 1), i = int(lane) % (kBins - 1);
+            const float cmin = dec(cb_lo[a]), cmax = dec(cb_hi[a]);
+            const float extent = cmax - cmin;
+            const bool empty = dec(cb_lo[0]) > dec(cb_hi[0]) || dec(cb_lo[1]) > dec(cb_hi[1]) || dec(cb_lo[2]) > dec(cb_hi[2]);
+            if (!empty && !(extent <= 0.0f)) {
+                RBox lbox, rbox;
+                lbox.reset();
+                rbox.reset();
+                uint32_t lsum = 0, rsum = 0;
+                float lo3[3], hi3[3];
+                for (int k = 0; k <= i; ++k) {
+                    const uint32_t cnt_k = L.bins.count[a][k];
+                    lsum += cnt_k;
+                    for (int q = 0; q < 3; ++q) {
+                        lo3[q] = cnt_k ? dec(L.bins.lo[a][k][q]) : FLT_MAX;
+                        hi3[q] = cnt_k ? dec(L.bins.hi[a][k][q]) : -FLT_MAX;
                     }
+                    lbox.grow(lo3, hi3);
                 }
-                L.left_count = i - f;
+                for (int k = kBins - 1; k > i; --k) {
+                    const uint32_t cnt_k = L.bins.count[a][k];
+                    rsum += cnt_k;
+                    for (int q = 0; q < 3; ++q) {
+                        lo3[q] = cnt_k ? dec(L.bins.lo[a][k][q]) : FLT_MAX;
+                        hi3[q] = cnt_k ? dec(L.bins.hi[a][k][q]) : -FLT_MAX;
+                    }
+                    rbox.grow(lo3, hi3);
+                }
+                cost = lsum * lbox.area() + rsum * rbox.area();
+                candidate = cost < FLT_MAX;
+                plane = cmin + extent * (float(i + 1) / kBins);
             }
         }
+        float best_cost = candidate ? cost : FLT_MAX;
+        int best_lane = candidate ? int(lane) : 64;
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float oc = __shfl_xor(best_cost, d, 64);
+            const int ol = __shfl_xor(best_lane, d, 64);
+            if (ol < 64 && (best_lane == 64 || oc < best_cost || (oc == best_cost && ol < best_lane))) {
+                best_cost = oc;
+                best_lane = ol;
+            }
+        }
+        RBox nb;
+        for (int q = 0; q < 3; ++q) {
+            nb.lo[q] = L.nlo[l][q];
+            nb.hi[q] = L.nhi[l][q];
+        }
+        const float parent_cost = c * nb.area();
+        if (best_lane == 64 || best_cost >= parent_cost) continue;
+        const int axis = best_lane / (kBins - 1);
+        const float pos = __shfl(plane, best_lane, 64);
+
+        // ---- partition (bvh.cpp:80-86) in its closed form
+        unsigned long long right_mask[kSmall / 64], left_mask[kSmall / 64];
+        uint32_t n_right = 0;
+        for (uint32_t k = 0; k < kSmall / 64; ++k) {
+            const uint32_t e = f + lane + 64 * k;
+            const bool valid = e < f + c;
+            const bool right = valid && !(L.c[axis][L.perm[valid ? e : f]] < pos);
+            right_mask[k] = __ballot(right);
+            left_mask[k] = __ballot(valid && !right);
+            n_right += __popcll(right_mask[k]);
+        }
+        const uint32_t n_left = c - n_right;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        uint32_t rights_seen = 0, lefts_seen = 0;
+        for (uint32_t k = 0; k < kSmall / 64; ++k) {
+            const uint32_t e = f + lane + 64 * k;
+            if ((right_mask[k] >> lane) & 1ull) L.pfront[rights_seen + __popcll(right_mask[k] & below)] = uint16_t(e);
+            if ((left_mask[k] >> lane) & 1ull) L.qback[n_left - 1 - (lefts_seen + __popcll(left_mask[k] & below))] = uint16_t(e);
+            rights_seen += __popcll(right_mask[k]);
+            lefts_seen += __popcll(left_mask[k]);
+        }
         __syncthreads();
-        if (!L.split) continue;
-        const uint32_t lc = L.left_count;
+        const uint32_t m = n_right < n_left ? n_right : n_left;
+        uint32_t K = 0;
+        for (uint32_t k = 0; k < kSmall / 64; ++k) {
+            const uint32_t r = lane + 64 * k;
+            K += __popcll(__ballot(r < m && L.pfront[r < m ? r : 0] < L.qback[r < m ? r : 0]));
+        }
+        uint32_t K2 = K;
+        if (K < n_right && uint32_t(L.pfront[K]) < (K > 0 ? uint32_t(L.qback[K - 1]) : f + c)) K2 = K + 1;
+        rights_seen = lefts_seen = 0;
+        for (uint32_t k = 0; k < kSmall / 64; ++k) {
+            const uint32_t e = f + lane + 64 * k;
+            const bool is_right = (right_mask[k] >> lane) & 1ull, is_left = (left_mask[k] >> lane) & 1ull;
+            if (is_right) {
+                const uint32_t r = rights_seen + __popcll(right_mask[k] & below);
+                const uint32_t dest = (r < K2) ? (r == 0 ? f + c - 1 : uint32_t(L.qback[r - 1]) - 1) : e - 1;
+                L.perm_next[dest] = L.perm[e];
+            } else if (is_left) {
+                const uint32_t lb = n_left - 1 - (lefts_seen + __popcll(left_mask[k] & below));
+                const uint32_t dest = (lb < K) ? uint32_t(L.pfront[lb]) : e;
+                L.perm_next[dest] = L.perm[e];
+            }
+            rights_seen += __popcll(right_mask[k]);
+            lefts_seen += __popcll(left_mask[k]);
+        }
+        __syncthreads();
+        for (uint32_t e = f + lane; e < f + c; e += 64) L.perm[e] = L.perm_next[e];
+        __syncthreads();
+        const uint32_t lc = n_left;
         if (lc == 0 || lc == c) continue;  // bvh.cpp:88-89
         const uint32_t ll = next_local;
         next_local += 2;
@@ -817,17 +964,25 @@ __global__ void kb_instance_bounds(const pt_geometry_instance *geoms, uint32_t n
 
 // bvh.cpp:283-331.  abox = boxes of the live clusters, structure of arrays with stride n.
 // status[0] = 0 on success, 1 when the iteration guard tripped.
+// Every "which cluster gives the smallest merged area with cluster x?" is a scan over the live
+// clusters spread over the workgroup's 1024 lanes; the searches depend on one another (each
+// merge or step of the walk decides the next query), so they run one after the other on one CU.
+// (Caching every slot's answer across merges was tried: exact, but the per-merge upkeep cost more
+// than the scans it saved.)
 constexpr uint32_t kTlasThreads = 1024;
+
 __global__ __launch_bounds__(kTlasThreads) void kb_tlas_pairing(pt_tlas_node *tlas, float *abox, uint32_t *active, uint32_t n, uint32_t *status) {
-    __shared__ float s_area[kTlasThreads / 64];
-    __shared__ int s_index[kTlasThreads / 64];
-    __shared__ int s_result;
+    __shared__ float s_area[2][kTlasThreads / 64];
+    __shared__ int s_index[2][kTlasThreads / 64];
     const uint32_t tid = threadIdx.x;
     int live = int(n);
     uint32_t next_node = 1 + n;
+    uint32_t parity = 0;
 
-    // Cluster of smallest merged area with cluster `who`; the lowest slot wins ties (strict < in a
-    // forward scan, bvh.cpp:286-297).  Every thread returns the same value.
+    // Cluster of smallest merged area with the box in slot `who`; the lowest slot wins ties
+    // (strict < in a forward scan, bvh.cpp:286-297).  Every thread returns the same value.
+    // `who` may lie one past the live range right after a merge whose first cluster sat in the
+    // last slot; the reference reads that stale slot too.
     auto best_partner = [&](int who) -> int {
         float mine_lo[3], mine_hi[3];
         for (int a = 0; a < 3; ++a) {
@@ -854,34 +1009,28 @@ __global__ __launch_bounds__(kTlasThreads) void kb_tlas_pairing(pt_tlas_node *tl
         for (int d = 32; d >= 1; d >>= 1) {
             const float oa = __shfl_xor(best_area, d, 64);
             const int ob = __shfl_xor(best, d, 64);
-            const bool take = ob >= 0 && (best < 0 || oa < best_area || (oa == best_area && ob < best));
-            if (take) {
+            if (ob >= 0 && (best < 0 || oa < best_area || (oa == best_area && ob < best))) {
                 best_area = oa;
                 best = ob;
             }
         }
         if ((tid & 63) == 0) {
-            s_area[tid >> 6] = best_area;
-            s_index[tid >> 6] = best;
+            s_area[parity][tid >> 6] = best_area;
+            s_index[parity][tid >> 6] = best;
         }
         __syncthreads();
-        if (tid == 0) {
-            float ba = s_area[0];
-            int bi = s_index[0];
-            for (uint32_t w = 1; w < kTlasThreads / 64; ++w) {
-                const float oa = s_area[w];
-                const int ob = s_index[w];
-                if (ob >= 0 && (bi < 0 || oa < ba || (oa == ba && ob < bi))) {
-                    ba = oa;
-                    bi = ob;
-                }
+        float ba = s_area[parity][0];
+        int bi = s_index[parity][0];
+        for (uint32_t w = 1; w < kTlasThreads / 64; ++w) {
+            const float oa = s_area[parity][w];
+            const int ob = s_index[parity][w];
+            if (ob >= 0 && (bi < 0 || oa < ba || (oa == ba && ob < bi))) {
+                ba = oa;
+                bi = ob;
             }
-            s_result = bi;
         }
-        __syncthreads();
-        const int r = s_result;
-        __syncthreads();  // s_result is rewritten by the next search
-        return r;
+        parity ^= 1u;  // the next search writes the other buffer while slow waves still read this one
+        return bi;
     };
 
     int a = 0;
@@ -897,6 +1046,7 @@ __global__ __launch_bounds__(kTlasThreads) void kb_tlas_pairing(pt_tlas_node *tl
         }
         const int c = best_partner(b);
         if (a == c) {
+            __syncthreads();  // every lane has finished reading the boxes that are about to change
             if (tid == 0) {
                 pt_tlas_node t;
                 for (int k = 0; k < 3; ++k) {
@@ -916,7 +1066,6 @@ __global__ __launch_bounds__(kTlasThreads) void kb_tlas_pairing(pt_tlas_node *tl
             }
             ++next_node;
             --live;
-            __threadfence_block();
             __syncthreads();
             b = (live > 1) ? best_partner(a) : -1;
         } else {
@@ -1077,7 +1226,7 @@ inline int BuildOnDevice(hipStream_t stream, const float *positions, uint32_t ve
 
     hipLaunchKernelGGL(kb_prims, dim3(Blocks(n)), dim3(256), 0, stream, d_positions, d_indices, d_meshes, mesh_count, P, n, order[0], node_of[0]);
     hipLaunchKernelGGL(kb_roots, dim3(Blocks(mesh_count)), dim3(256), 0, stream, nodes, d_meshes, mesh_count, keys, small_list, counters + 4);
-    hipLaunchKernelGGL(kb_bounds_keys, dim3(Blocks(n)), dim3(256), 0, stream, nodes, 0u, mesh_count, node_of[0], order[0], P, n, keys);
+    hipLaunchKernelGGL(kb_bounds_keys, dim3(Blocks(n, kAggBlock)), dim3(kAggBlock), 0, stream, nodes, 0u, mesh_count, node_of[0], order[0], P, n, keys);
     hipLaunchKernelGGL(kb_bounds_decode, dim3(Blocks(mesh_count)), dim3(256), 0, stream, nodes, 0u, mesh_count, keys, order[0], P);
     uint32_t node_count = mesh_count;
     PTB_TRY(hipMemcpyAsync(counters, &node_count, 4, hipMemcpyHostToDevice, stream));
@@ -1091,8 +1240,8 @@ inline int BuildOnDevice(hipStream_t stream, const float *positions, uint32_t ve
         const uint32_t width = end - begin;
         PTB_TRY(hipMemsetAsync(counters + 3, 0, 4, stream));
         hipLaunchKernelGGL(kb_level_init, dim3(Blocks(width)), dim3(256), 0, stream, nodes, begin, end, bins, counters + 3);
-        hipLaunchKernelGGL(kb_centroid_bounds, dim3(Blocks(n)), dim3(256), 0, stream, nodes, begin, end, node_of[cur], order[cur], P, n);
-        hipLaunchKernelGGL(kb_bin, dim3(Blocks(n)), dim3(256), 0, stream, nodes, begin, end, node_of[cur], order[cur], P, n, bins);
+        hipLaunchKernelGGL(kb_centroid_bounds, dim3(Blocks(n, kAggBlock)), dim3(kAggBlock), 0, stream, nodes, begin, end, node_of[cur], order[cur], P, n);
+        hipLaunchKernelGGL(kb_bin, dim3(Blocks(n, kAggBlock)), dim3(kAggBlock), 0, stream, nodes, begin, end, node_of[cur], order[cur], P, n, bins);
         hipLaunchKernelGGL(kb_split, dim3(Blocks(width, 64)), dim3(64), 0, stream, nodes, begin, end, bins);
         hipLaunchKernelGGL(kb_flags, dim3(Blocks(n)), dim3(256), 0, stream, nodes, begin, end, node_of[cur], order[cur], P, n, flag);
         hipLaunchKernelGGL(kb_scan_tiles, dim3(tiles), dim3(kScanBlock), 0, stream, flag, n, scan, tile_sums);
@@ -1112,7 +1261,7 @@ inline int BuildOnDevice(hipStream_t stream, const float *positions, uint32_t ve
         begin = end;
         end = node_count;
         if (begin < end) {
-            hipLaunchKernelGGL(kb_bounds_keys, dim3(Blocks(n)), dim3(256), 0, stream, nodes, begin, end, node_of[cur], order[cur], P, n, keys);
+            hipLaunchKernelGGL(kb_bounds_keys, dim3(Blocks(n, kAggBlock)), dim3(kAggBlock), 0, stream, nodes, begin, end, node_of[cur], order[cur], P, n, keys);
             hipLaunchKernelGGL(kb_bounds_decode, dim3(Blocks(end - begin)), dim3(256), 0, stream, nodes, begin, end, keys, order[cur], P);
         }
     }

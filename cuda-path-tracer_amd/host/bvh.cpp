@@ -326,6 +326,22 @@ void TLAS::Build(const float *positions, const uint32_t *indices, const std::vec
     m_tlas_nodes[0] = m_tlas_nodes[active[a]];
 }
 
+void TLAS::BuildOnDevice(pt_ctx *ctx, const float *positions, uint32_t vertex_count, const uint32_t *indices, uint32_t index_count,
+                         const std::vector<pt_geometry_instance> &instances) {
+    m_dirty = true;
+    pt_bvh *h = nullptr;
+    if (pt_bvh_build(ctx, positions, vertex_count, indices, index_count, instances.data(), uint32_t(instances.size()), &h) != PT_OK)
+        throw Exception(std::string("TLAS::BuildOnDevice: ") + pt_last_error(ctx));
+    uint32_t n_tlas = 0, n_blas = 0, n_nodes = 0, n_tris = 0;
+    pt_bvh_sizes(h, &n_tlas, &n_blas, &n_nodes, &n_tris);
+    m_tlas_nodes.resize(n_tlas);
+    m_device_blases.resize(n_blas);
+    m_blas_nodes.resize(n_nodes);
+    m_tri_indices.resize(n_tris);
+    pt_bvh_get(h, m_tlas_nodes.data(), m_device_blases.data(), m_blas_nodes.data(), m_tri_indices.data());
+    pt_bvh_free(h);
+}
+
 void TLAS::UpdateDevice(pt_scene_desc &scene) {
     scene.tlas_nodes = m_tlas_nodes.data();
     scene.tlas_node_count = uint32_t(m_tlas_nodes.size());

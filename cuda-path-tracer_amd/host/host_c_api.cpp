@@ -193,6 +193,10 @@ int pth_scene_finalize(pth_scene *s) {
     if (!s) return Fail("pth_scene_finalize: null scene");
     return Guard([&] { s->scene.Finalize(); });
 }
+int pth_scene_finalize_device(pth_scene *s, pt_ctx *ctx) {
+    if (!s || !ctx) return Fail("pth_scene_finalize_device: null argument");
+    return Guard([&] { s->scene.Finalize(ctx); });
+}
 int pth_scene_get_desc(pth_scene *s, pt_scene_desc *out) {
     if (!s || !out) return Fail("pth_scene_get_desc: null argument");
     return Guard([&] { *out = s->scene.GetDeviceScene(); });

@@ -54,6 +54,9 @@ public:
     void Build(const float *positions, const uint32_t *indices,
                const std::vector<pt_geometry_instance> &instances,
                SplitStrategy split_type = SplitStrategy::SAH);
+    // The same arrays, bit for bit, built on the GPU behind `ctx` (pt_bvh_build).
+    void BuildOnDevice(pt_ctx *ctx, const float *positions, uint32_t vertex_count, const uint32_t *indices, uint32_t index_count,
+                       const std::vector<pt_geometry_instance> &instances);
     // Points the description at this object's arrays (the reference uploads here, bvh.cpp:334-352;
     // the upload itself now happens inside pt_scene_upload).
     void UpdateDevice(pt_scene_desc &scene);
@@ -159,6 +162,7 @@ public:
     int AddInstance(const TriangleMesh &mesh, int material_id, const Mat4 &transform, int blas_index);
     // Tail of LoadScene, scene.cpp:676-686: builds the TLAS and the light tables.
     void Finalize();
+    void Finalize(pt_ctx *ctx);  // same, with the acceleration structures built on the GPU behind ctx
 
     int Width() const { return m_camera.Width(); }
     int Height() const { return m_camera.Height(); }

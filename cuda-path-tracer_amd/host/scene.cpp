@@ -269,6 +269,17 @@ void Scene::Finalize() {
     m_camera.Dirty() = true;
 }
 
+void Scene::Finalize(pt_ctx *ctx) {
+    if (!ctx) throw Exception("Scene::Finalize: null context");
+    if (m_geometries.empty()) throw Exception("Scene::Finalize: the scene has no objects");
+    m_bvh->BuildOnDevice(ctx, m_positions.data(), uint32_t(m_positions.size() / 3), m_indices.data(), uint32_t(m_indices.size()), m_geometries);
+    ComputeLightData();
+    m_dirty = true;
+    m_texture_pool.dirty = true;
+    m_bvh->Dirty() = true;
+    m_camera.Dirty() = true;
+}
+
 void Scene::FillDesc() {
     pt_scene_desc &d = m_desc;
     d.max_depth = uint32_t(m_max_depth);

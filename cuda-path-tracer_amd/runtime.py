@@ -235,8 +235,12 @@ class HostScene:
         _host_check(self._lib.pth_scene_add_instance(self._h, first_index, index_count, vertex_count, material_id, abi.fptr(t), blas_index, C.byref(out)))
         return out.value
 
-    def finalize(self):
-        _host_check(self._lib.pth_scene_finalize(self._h))
+    def finalize(self, ctx: "Context" = None):
+        """Scene::Finalize: builds the acceleration structures (on the GPU behind `ctx` when given) and the light tables."""
+        if ctx is None:
+            _host_check(self._lib.pth_scene_finalize(self._h))
+        else:
+            _host_check(self._lib.pth_scene_finalize_device(self._h, ctx.handle))
 
     def desc(self) -> abi.SceneDesc:
         """Host-pointer scene description (valid while this object is alive and unchanged)."""

@@ -71,8 +71,9 @@ class SceneSpec:
         self.ops.append(op)
         return sum(1 for o in self.ops if o["op"] == "mesh") - 1
 
-    def build(self, width: int | None = None, height: int | None = None, max_depth: int | None = None) -> HostScene:
-        """Replays the calls against a fresh HostScene and finalises it (BVH + light tables)."""
+    def build(self, width: int | None = None, height: int | None = None, max_depth: int | None = None, ctx=None) -> HostScene:
+        """Replays the calls against a fresh HostScene and finalises it (BVH + light tables); with a
+        Context the acceleration structures are built on its GPU (identical arrays)."""
         hs = HostScene()
         hs.set_integrator(max_depth or self.max_depth, self.max_iterations)
         c = self.camera
@@ -113,7 +114,7 @@ class SceneSpec:
                 hs.add_instance(first, icount, vcount, o["material"], np.asarray(o["transform"], F32), o["blas"])
             else:
                 raise ValueError(f"unknown op {k}")
-        hs.finalize()
+        hs.finalize(ctx)
         return hs
 
     # ---- cooked container

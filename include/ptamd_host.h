@@ -64,6 +64,8 @@ int pth_scene_add_instance(pth_scene *scene, uint32_t first_index, uint32_t inde
                            int material_id, const float transform[16], int blas_index, int *instance_id);
 /* TLAS::Build + ComputeLightData (scene.cpp:676-686, :580-647) */
 int pth_scene_finalize(pth_scene *scene);
+/* Same, with the BLAS / TLAS build done by pt_bvh_build on the GPU behind ctx (identical arrays). */
+int pth_scene_finalize_device(pth_scene *scene, pt_ctx *ctx);
 /* host-pointer description, valid until the scene changes or is destroyed */
 int pth_scene_get_desc(pth_scene *scene, pt_scene_desc *out);
 /* Scene::UpdateDevice (scene.cpp:52-96) */

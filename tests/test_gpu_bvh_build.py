@@ -89,6 +89,21 @@ def test_device_build_random_soups_and_degenerate_inputs(pt, ora, gpu_ctx):
         assert len(dev["blases"]) == 4 and dev["blases"][2]["node_count"] == 0
 
 
+def test_scene_finalize_on_device_gives_the_same_scene(pt, gpu_ctx):
+    """Scene::Finalize through the facade with the device builder: every array of the description,
+    light tables included, equals the host-built scene's."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = pt.SceneSpec.load(os.path.join(root, "scenes", "helmet.npz"))
+    host = spec.build(width=64, height=64, max_depth=4).arrays()
+    dev = spec.build(width=64, height=64, max_depth=4, ctx=gpu_ctx).arrays()
+    for k, v in host.items():
+        if isinstance(v, np.ndarray):
+            assert np.array_equal(_bits(v), _bits(dev[k])), k
+        else:
+            assert v == dev[k], k
+
+
 def test_device_build_small_and_error_cases(pt, gpu_ctx):
     tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
     eye = np.eye(4, dtype=np.float32)
@@ -131,6 +146,19 @@ def test_device_built_scene_renders_like_the_host_built_one(pt, gpu_ctx, scene_f
     gpu_ctx.upload(desc)
     b = gpu_ctx.trace_closest_host(rays)
     assert np.array_equal(_bits(a), _bits(b)) and (a["t"] > 0).mean() > 0.2
+
+
+@pytest.mark.parametrize("n_inst,lattice", [(2, 1), (3, 1), (7, 2), (500, 4), (3000, 8), (3000, 64), (5000, 1000)])
+def test_device_tlas_pairing_with_exact_ties(pt, gpu_ctx, n_inst, lattice):
+    """Instances of one mesh translated onto a coarse integer lattice: many pairs have exactly the
+    same merged surface area (and many instances coincide), so the pairing order is decided by the
+    slot-number tie rule all the way; any slip in the cached partner answers changes the tree."""
+    rs = np.random.RandomState(n_inst + lattice)
+    pos, idx = _soup(rs, 16, quantise=4)
+    T = np.tile(np.eye(4, dtype=np.float32), (n_inst, 1, 1))
+    T[:, 3, :3] = rs.randint(0, lattice, size=(n_inst, 3)).astype(np.float32) * 8
+    geo = _geometry(pt, {0: (0, len(idx), len(pos))}, [(0, T[k]) for k in range(n_inst)])
+    _same(gpu_ctx.bvh_build(pos, idx, geo), pt.bvh_build(pos, idx, geo), f"{n_inst} instances on a {lattice}^3 lattice")
 
 
 def test_device_build_many_instances_is_faster_than_the_sequential_build(pt, gpu_ctx):

@@ -122,7 +122,9 @@ def test_bounds_hit_counts_equal_the_counted_query(pt, ora, gpu_ctx, devbuf, sce
     assert not tri_image[..., 2].any()
 
 
-def test_debug_integrator_facade_and_argument_checks(pt, ora, gpu_ctx, devbuf, tiny_scene):
+def test_debug_integrator_facade_and_argument_checks(pt, ora, gpu_ctx, devbuf):
+    from conftest import make_tiny_scene
+    tiny_scene = make_tiny_scene(pt)  # a scene of its own: Scene::UpdateDevice clears the scene's dirty flags
     w, h = 64, 48
     rgba = devbuf(w * h * 4)
     st = _state(pt, mode="PT_DEBUG_GEOMETRIC_NORMALS")
