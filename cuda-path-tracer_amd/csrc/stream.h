@@ -18,6 +18,10 @@
 #pragma once
 #include "traverse.h"
 
+#ifndef PT_POSTPONE_LEAVES
+#define PT_POSTPONE_LEAVES 0  // 1: lanes set leaves aside and keep testing boxes (see Traversal::kPostpone)
+#endif
+
 namespace ptd {
 
 template <int MODE, bool COUNT>
@@ -35,6 +39,7 @@ struct Traversal {
     bool in_blas;
     uint32_t cur;
     uint32_t tri_next, tri_left;  // progress inside the current BLAS leaf (tri_left == 0: not opened)
+    uint32_t held;   // a leaf set aside while the lane goes on testing boxes (kNoRef: none)
     HitRec hit;
     bool found;      // MODE_ANY: an occluder was found
     TraceCounters ctr;
@@ -70,18 +75,39 @@ struct Traversal {
         in_blas = false;
         cur = S.root_ref;
         tri_next = tri_left = 0;
+        held = kNoRef;
         return true;
     }
 
     // True when a closest hit exists (valid once finished; kernel/intersection.h:229-232).
     PTD bool closest_valid() const { return !(best < 0.0f || best == FLT_MAX); }
 
+    // Leaves wait in a queue of up to three: the one being tested (tri_left > 0), `held`, and cur.
+    // With kPostpone a lane keeps popping and testing boxes while leaves wait (it only has to stop
+    // when cur is a leaf and `held` is taken): the bound used for culling is then a little stale, so
+    // a superset of the reference's nodes is visited, in the same order, and the leaves are still
+    // tested in the order they were met - the same triangle wins, ties included (only a ray that
+    // overflows the reference's 64-entry stack could tell the difference, because the set of
+    // dropped pushes depends on what was culled).  Measured on bounce rays: box rounds 0.43 -> 0.46
+    // of the lanes busy, 2 % faster; off by default for the overflow case.  The counting variant
+    // never postpones: its visit counts are the reference's.
+    static constexpr bool kPostpone = PT_POSTPONE_LEAVES && !COUNT;
+    PTD bool leaf_pending() const { return in_blas && (tri_left != 0 || held != kNoRef); }
     PTD bool wants_interior() const { return cur < kNoRef; }
-    PTD bool wants_triangle() const { return cur > kNoRef && in_blas; }
+    PTD bool wants_triangle() const { return in_blas && (cur > kNoRef || tri_left != 0 || held != kNoRef); }
+    PTD bool must_triangle() const { return in_blas && (kPostpone ? (cur > kNoRef && held != kNoRef) : (cur > kNoRef || tri_left != 0)); }
     PTD bool wants_enter() const { return cur > kNoRef && !in_blas; }
-    PTD bool wants_pop() const { return cur == kNoRef && sp != base && sp <= kLdsDepth; }
-    PTD bool wants_deep_pop() const { return cur == kNoRef && sp != base && sp > kLdsDepth; }  // entry is in the global spill area
-    PTD bool wants_level() const { return cur == kNoRef && sp == base; }
+    PTD bool may_pop() const { return cur == kNoRef && sp != base && (kPostpone || !leaf_pending()); }
+    PTD bool wants_pop() const { return may_pop() && sp <= kLdsDepth; }
+    PTD bool wants_deep_pop() const { return may_pop() && sp > kLdsDepth; }  // entry is in the global spill area
+    PTD bool wants_level() const { return cur == kNoRef && sp == base && !leaf_pending(); }
+    // cur is a leaf and `held` is free: set the leaf aside so that the lane can pop on
+    PTD void set_leaf_aside() {
+        if (kPostpone && in_blas && cur > kNoRef && held == kNoRef) {
+            held = cur;
+            cur = kNoRef;
+        }
+    }
 
     // One pop (kernel/intersection.h:54-60): the entry is dropped when its box starts beyond
     // the current bound; then cur stays empty and the lane pops again next round.
@@ -168,10 +194,18 @@ struct Traversal {
     // The next triangle of the current leaf (kernel/intersection.h:63-112).  Returns true in
     // MODE_ANY when the ray is occluded (finished).
     PTD bool op_triangle(const DScene &S) {
-        if (tri_left == 0) {  // first visit: open the leaf
+        if (tri_left == 0) {  // open the oldest waiting leaf
             if (COUNT) ctr.blas_leaves++;
-            tri_next = cur & 0x0FFFFFFFu;
-            tri_left = ((cur >> 28) & 7u) + 1u;
+            uint32_t leaf;
+            if (held != kNoRef) {
+                leaf = held;
+                held = kNoRef;
+            } else {
+                leaf = cur;
+                cur = kNoRef;
+            }
+            tri_next = leaf & 0x0FFFFFFFu;
+            tri_left = ((leaf >> 28) & 7u) + 1u;
             if (tri_left == 8u) {
                 const uint2 big = S.big_leaves[tri_next];
                 tri_next = big.x;
@@ -195,7 +229,7 @@ struct Traversal {
             lv = v;
         }
         ++tri_next;
-        if (--tri_left == 0) cur = kNoRef;
+        --tri_left;
         return false;
     }
 
@@ -315,6 +349,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, con
         // ---- box-test rounds, while enough lanes take part.  The node loads are issued before
         // the pops so that the LDS round trip hides behind them.
         for (;;) {
+            if (active) tr.set_leaf_aside();
 #ifdef PT_POP_FIRST
             if (active && tr.wants_pop()) {
                 PT_PHASE(ev, 3);

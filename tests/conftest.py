@@ -138,3 +138,47 @@ def devbuf():
         return DeviceBuf(torch, nbytes)
 
     return make
+
+
+def make_vine_scene(pt, depth, nearest_is_deepest):
+    """One mesh of depth+1 parallel triangles and a hand-made BLAS shaped like a vine: every interior
+    node has one leaf child and one interior child, and all interior boxes coincide, so a ray along
+    the stem finds the interior child nearer at every level and pushes one leaf per level."""
+    n_tri = depth + 1
+    xs = (400.0 - np.arange(n_tri)) if nearest_is_deepest else (100.0 + np.arange(n_tri))
+    pos = np.zeros((n_tri, 3, 3), np.float32)
+    pos[:, :, 0] = xs[:, None]
+    pos[:, 1, 1] = 1.0
+    pos[:, 2, 2] = 1.0
+    pos = pos.reshape(-1, 3)
+    nrm = np.tile(np.array([[-1, 0, 0]], np.float32), (len(pos), 1))
+    hs = pt.HostScene()
+    hs.set_integrator(2, 1)
+    hs.set_camera([-10, 0.25, 0.25], [0, 0.25, 0.25], [0, 1, 0], 45.0, 8, 8)
+    tex = hs.add_constant_texture3([1, 1, 1])
+    hs.add_material(pt.abi.PT_MAT_LAMBERTIAN, tex)
+    first = hs.add_mesh(pos, nrm, np.zeros((len(pos), 2), np.float32), np.arange(len(pos), dtype=np.uint32))
+    hs.add_instance(first, len(pos), len(pos), 0, np.eye(4, dtype=np.float32).reshape(-1), hs.new_blas_index())
+    hs.finalize()
+    nodes = np.zeros(2 * depth + 1, pt.abi.BVH_NODE)
+
+    def tri_box(k):
+        return [xs[k] - 0.01, 0.0, 0.0], [xs[k] + 0.01, 1.0, 1.0]
+    for k in range(depth):  # stem node k: index 0 for the root, else 2k; children 2k+1 (leaf k) and 2k+2
+        i = 0 if k == 0 else 2 * k
+        nodes[i]["min"], nodes[i]["max"] = [-1, -1, -1], [500, 2, 2]
+        nodes[i]["first_primitive"], nodes[i]["primitive_count"] = 2 * k + 1, 0
+        leaf = 2 * k + 1
+        nodes[leaf]["min"], nodes[leaf]["max"] = tri_box(k)
+        nodes[leaf]["first_primitive"], nodes[leaf]["primitive_count"] = k, 1
+    last = 2 * depth  # the deepest stem node's second child is the last leaf
+    nodes[last]["min"], nodes[last]["max"] = tri_box(depth)
+    nodes[last]["first_primitive"], nodes[last]["primitive_count"] = depth, 1
+    blases = np.zeros(1, pt.abi.BLAS)
+    blases[0] = (0, len(nodes), 0, n_tri)
+    keep = {"nodes": nodes, "blases": blases, "tris": np.arange(n_tri, dtype=np.uint32), "hs": hs}
+    desc = pt.abi.SceneDesc.from_buffer_copy(hs.desc())
+    desc.blas_nodes, desc.blas_node_count = nodes.ctypes.data, len(nodes)
+    desc.blases, desc.blas_count = blases.ctypes.data, 1
+    desc.tri_indices, desc.tri_index_count = pt.abi.uptr(keep["tris"]), n_tri
+    return desc, keep

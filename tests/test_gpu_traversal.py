@@ -9,7 +9,7 @@ holds; the looser bar is the fallback documented for other compilers."""
 import numpy as np
 import pytest
 
-from conftest import rays_from_arrays
+from conftest import make_vine_scene, rays_from_arrays
 
 pytestmark = pytest.mark.gpu
 FLT_MAX = np.float32(3.4028235e38)
@@ -157,6 +157,37 @@ def test_exact_ties_resolve_like_the_oracle(pt, ora, gpu_ctx):
     assert np.array_equal(hits["inst"], ref["inst"]) and np.array_equal(hits["prim"], ref["prim"])
     assert np.array_equal(hits["t"].view(np.uint32), ref["t"].view(np.uint32))
     assert (ref["inst"] >= 0).mean() > 0.5
+
+
+@pytest.mark.parametrize("depth,nearest_is_deepest", [(40, True), (63, True), (64, True), (65, True), (100, True), (100, False)])
+def test_stack_overflow_drops_pushes_like_the_reference(pt, ora, gpu_ctx, depth, nearest_is_deepest):
+    """The reference's traversal stack holds 64 entries and silently ignores pushes beyond that
+    (utils/stack.h:8-11).  A vine-shaped BLAS drives the stack past 64: from there on the nearer
+    child's push is lost, the walk turns back, and the ray reports a farther triangle than the true
+    closest one.  The kernel keeps deeper entries than its LDS part in a spill area and reproduces
+    which pushes are lost, so it returns the same (wrong) triangle as the oracle."""
+    desc, keep = make_vine_scene(pt, depth, nearest_is_deepest)
+    gpu_ctx.upload(desc)
+    gpu_ctx.reset_stats()
+    n = 256
+    rs = np.random.RandomState(depth)
+    o = np.concatenate([np.full((n, 1), -10.0), rs.uniform(0.05, 0.45, size=(n, 2))], axis=1).astype(np.float32)
+    d = np.tile(np.array([[1, 0, 0]], np.float32), (n, 1))
+    rays = rays_from_arrays(pt, o, d)
+    hits = gpu_ctx.trace_closest_host(rays)
+    ref = ora.trace_closest(desc, rays, nthreads=1)
+    assert np.array_equal(hits["prim"], ref["prim"]) and np.array_equal(hits["t"].view(np.uint32), ref["t"].view(np.uint32))
+    assert (ref["prim"] >= 0).all()
+    occluded = gpu_ctx.trace_any_host(rays)
+    assert np.array_equal(occluded, ora.trace_any(desc, rays))
+    st = gpu_ctx.stats()
+    true_nearest = depth if nearest_is_deepest else 0
+    if depth >= 64:
+        assert st.stack_drops > 0 and st.stack_spills > 0
+        if nearest_is_deepest:
+            assert (ref["prim"] != true_nearest).all()  # the closest triangle sits behind a lost push
+    else:
+        assert st.stack_drops == 0 and (ref["prim"] == true_nearest).all()
 
 
 def test_resolve_hits_matches_oracle_intersection(pt, ora, gpu_ctx, scene_factory, tiny_scene):

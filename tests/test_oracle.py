@@ -6,7 +6,7 @@ and alias-table reconstruction of the input distribution."""
 import numpy as np
 import pytest
 
-from conftest import rays_from_arrays
+from conftest import make_vine_scene, rays_from_arrays
 
 FLT_MAX = np.float32(3.4028235e38)
 
@@ -324,3 +324,52 @@ def test_debug_attribute_views(pt, ora, tiny_scene):
     assert (rgba[..., :3][bg] == 102).all()  # (int)(0.4f * 255.0) = 102
     none_img, none_rgba = ora.debug_render(desc, w, h, _debug_state(pt))
     assert not none_img.any() and not none_rgba.any()
+
+
+@pytest.mark.parametrize("depth,nearest_is_deepest", [(40, True), (63, True), (64, True), (65, True), (100, True), (100, False)])
+def test_oracle_stack_overflow_follows_the_reference_stack(pt, ora, depth, nearest_is_deepest):
+    """utils/stack.h:8-11: 64 entries, pushes beyond that are ignored.  The vine BLAS pushes one leaf
+    per level; an independent replay of IntersectBLAS (kernel/intersection.h:52-137) with a capped
+    Python list must name the same triangle as the oracle."""
+    desc, keep = make_vine_scene(pt, depth, nearest_is_deepest)
+    nodes = keep["nodes"]
+    o = np.array([[-10.0, 0.25, 0.25]], np.float32)
+    d = np.array([[1.0, 0.0, 0.0]], np.float32)
+    ref = ora.trace_closest(desc, rays_from_arrays(pt, o, d))
+
+    def box_entry(i):  # the ray runs along +x through every box of the vine
+        return float(np.float32(nodes[i]["min"][0]) - np.float32(-10.0))
+
+    stack, best, prim = [(0, 0.0)], np.inf, -1
+
+    def push(item):
+        if len(stack) < 64:
+            stack.append(item)
+    while stack:
+        i, entry = stack.pop()
+        if entry >= best:
+            continue
+        nd = nodes[i]
+        if nd["primitive_count"] > 0:
+            k = int(nd["first_primitive"])
+            t = float(np.float32(nd["min"][0] + np.float32(0.01)) + 10.0)  # the triangle's plane
+            if t < best:
+                best, prim = t, k
+            continue
+        left, right = int(nd["first_primitive"]), int(nd["first_primitive"]) + 1
+        tl, tr = box_entry(left), box_entry(right)
+        hl, hr = tl < best, tr < best
+        if hl and hr:
+            if tl < tr:
+                push((right, tr))
+                push((left, tl))
+            else:
+                push((left, tl))
+                push((right, tr))
+        elif hl:
+            push((left, tl))
+        elif hr:
+            push((right, tr))
+    assert int(ref["prim"][0]) == prim
+    true_nearest = depth if nearest_is_deepest else 0
+    assert (prim == true_nearest) == (depth < 64 or not nearest_is_deepest)
