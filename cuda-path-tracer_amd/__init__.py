@@ -2,5 +2,6 @@
 (HIP kernels + C ABI + host C++ facade) and the scene ingestion helpers."""
 from . import abi, sharding  # noqa: F401
 from .runtime import (Context, DebugIntegrator, HostScene, PathIntegrator, PtError, alias_build, bvh_build, camera_make,  # noqa: F401
-                      gltf_local_matrix, matrix_derive, matrix_mul, save_hdr, save_png, transform_matrix)
+                      checkpoint_read, gltf_local_matrix, matrix_derive, matrix_mul, render_offscreen, save_hdr, save_png,
+                      transform_matrix)
 from .scene_io import SceneSpec, load_scene_json, unit_cube, uv_sphere  # noqa: F401

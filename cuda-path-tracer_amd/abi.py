@@ -122,6 +122,18 @@ class IntegratorState(C.Structure):
                 ("debug_mode", C.c_int32)]
 
 
+class OffscreenOptions(C.Structure):
+    """pth_offscreen_options."""
+    _fields_ = [("iterations", C.c_uint32), ("batch", C.c_uint32), ("save_every", C.c_uint32), ("resume", C.c_int32),
+                ("output_prefix", C.c_char_p), ("checkpoint_path", C.c_char_p)]
+
+
+class OffscreenResult(C.Structure):
+    """pth_offscreen_result."""
+    _fields_ = [("first_iteration", C.c_uint32), ("iterations_done", C.c_uint32), ("images_written", C.c_uint32),
+                ("seconds", C.c_double)]
+
+
 # DebugVisualizeMode / BVH_VisualizeMode, kernel/device_types.h:10-24
 (PT_DEBUG_NONE, PT_DEBUG_GEOMETRIC_NORMALS, PT_DEBUG_ALBEDO, PT_DEBUG_UV, PT_DEBUG_DEPTH, PT_DEBUG_METALLIC,
  PT_DEBUG_ROUGHNESS) = range(7)
@@ -134,7 +146,7 @@ PT_SYMBOLS = [
     "pt_ctx_create", "pt_ctx_destroy", "pt_last_error", "pt_version", "pt_set_stream", "pt_synchronize",
     "pt_set_profiling", "pt_get_stats", "pt_reset_stats", "pt_scene_upload", "pt_camera_update", "pt_scene_free",
     "pt_integrator_init", "pt_integrator_destroy", "pt_integrator_resize", "pt_integrator_reset", "pt_render",
-    "pt_render_async", "pt_render_batch", "pt_film_download", "pt_film_copy_to_device", "pt_film_copy_from_device", "pt_tonemap",
+    "pt_render_async", "pt_render_batch", "pt_film_download", "pt_film_copy_to_device", "pt_film_copy_from_device", "pt_film_upload", "pt_display_download", "pt_tonemap",
     "pt_trace_closest", "pt_trace_any", "pt_resolve_hits", "pt_trace_closest_counted", "pt_trace_closest_host",
     "pt_trace_any_host", "pt_resolve_hits_host", "pt_generate_incoherent_rays", "pt_capture_bounce_rays",
     "pt_set_trace_mode", "pt_debug_render", "pt_bvh_build", "pt_bvh_sizes", "pt_bvh_get", "pt_bvh_timing", "pt_bvh_free"]
@@ -145,7 +157,7 @@ PTH_SYMBOLS = [
     "pth_scene_add_material", "pth_scene_add_texture1", "pth_scene_add_texture3", "pth_scene_add_image",
     "pth_scene_new_blas_index", "pth_scene_add_instance", "pth_scene_finalize", "pth_scene_finalize_device", "pth_scene_get_desc",
     "pth_scene_update_device", "pth_integrator_create", "pth_integrator_destroy", "pth_integrator_init",
-    "pth_integrator_resize", "pth_integrator_reset", "pth_integrator_render", "pth_debug_render", "pth_save_png", "pth_save_hdr"]
+    "pth_integrator_resize", "pth_integrator_reset", "pth_integrator_render", "pth_debug_render", "pth_render_offscreen", "pth_checkpoint_read", "pth_save_png", "pth_save_hdr"]
 
 _lib = None
 
@@ -196,6 +208,8 @@ def load_library() -> C.CDLL:
         "pt_film_copy_to_device": (i32, [vp, vp]),
         "pt_film_copy_from_device": (i32, [vp, vp]),
         "pt_tonemap": (i32, [vp, vp, i32, i32, i32, vp]),
+        "pt_film_upload": (i32, [vp, vp]),
+        "pt_display_download": (i32, [vp, i32, vp]),
         "pt_trace_closest": (i32, [vp, vp, sz, vp]),
         "pt_trace_any": (i32, [vp, vp, sz, vp]),
         "pt_resolve_hits": (i32, [vp, vp, vp, sz, vp]),
@@ -245,6 +259,8 @@ def load_library() -> C.CDLL:
         "pth_integrator_reset": (i32, [vp, i32, i32]),
         "pth_integrator_render": (i32, [vp, i32, i32, vp, vp, i32]),
         "pth_debug_render": (i32, [vp, i32, i32, vp, C.POINTER(IntegratorState), vp]),
+        "pth_render_offscreen": (i32, [vp, vp, C.POINTER(OffscreenOptions), C.POINTER(OffscreenResult)]),
+        "pth_checkpoint_read": (i32, [C.c_char_p, C.POINTER(i32), C.POINTER(i32), up, vp]),
         "pth_save_png": (i32, [C.c_char_p, vp, i32, i32]),
         "pth_save_hdr": (i32, [C.c_char_p, vp, i32, i32, i32]),
     }

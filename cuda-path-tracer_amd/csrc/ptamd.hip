@@ -1089,6 +1089,33 @@ int pt_film_copy_from_device(pt_ctx *ctx, const float *rgb_device) {
     return PT_OK;
 }
 
+int pt_film_upload(pt_ctx *ctx, const float *rgb_host) {
+    if (!ctx || !rgb_host) return PT_ERR_INVALID;
+    if (!ctx->integrator_ready) return Fail(ctx, PT_ERR_STATE, "no film: integrator not initialised");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, Join(ctx));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->film, rgb_host, size_t(ctx->width) * ctx->height * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, SyncAll(ctx));
+    return PT_OK;
+}
+
+// The displayed image of the context's film after `iterations` samples, in host memory.
+int pt_display_download(pt_ctx *ctx, int iterations, uint8_t *rgba_host) {
+    if (!ctx || !rgba_host) return PT_ERR_INVALID;
+    if (!ctx->integrator_ready) return Fail(ctx, PT_ERR_STATE, "no film: integrator not initialised");
+    if (iterations <= 0) return Fail(ctx, PT_ERR_INVALID, "pt_display_download: iterations must be positive");
+    DeviceGuard guard(ctx->device);
+    const size_t bytes = size_t(ctx->width) * ctx->height * 4;
+    uint8_t *staging = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&staging), bytes));
+    int st = pt_tonemap(ctx, nullptr, ctx->width, ctx->height, iterations, staging);
+    hipError_t e = hipSuccess;
+    if (st == PT_OK) e = hipMemcpy(rgba_host, staging, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(staging);
+    if (e != hipSuccess) return Fail(ctx, PT_ERR_DEVICE, "pt_display_download: %s", hipGetErrorString(e));
+    return st;
+}
+
 int pt_tonemap(pt_ctx *ctx, const float *film_device, int width, int height, int iterations, uint8_t *rgba_device) {
     if (!ctx || !rgba_device) return PT_ERR_INVALID;
     if (width <= 0 || height <= 0 || iterations <= 0) return Fail(ctx, PT_ERR_INVALID, "pt_tonemap: bad size or iteration count");

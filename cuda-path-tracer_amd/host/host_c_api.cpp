@@ -239,6 +239,18 @@ int pth_debug_render(pt_ctx *ctx, int w, int h, pth_scene *s, const pt_integrato
         DebugIntegrator(ctx).Render(w, h, s->scene, rgba_device, 0, st);
     });
 }
+int pth_render_offscreen(pt_ctx *ctx, pth_scene *s, const pth_offscreen_options *options, pth_offscreen_result *result) {
+    if (!ctx || !s || !options || !result) return Fail("pth_render_offscreen: null argument");
+    return Guard([&] { RenderOffscreen(ctx, s->scene, *options, *result); });
+}
+int pth_checkpoint_read(const char *path, int *width, int *height, uint32_t *iterations, float *film_rgb) {
+    if (!path || !width || !height || !iterations) return Fail("pth_checkpoint_read: null argument");
+    return Guard([&] {
+        std::vector<float> film;
+        if (!ReadCheckpoint(path, *width, *height, *iterations, film_rgb ? &film : nullptr)) throw Exception(std::string("no checkpoint at ") + path);
+        if (film_rgb) std::memcpy(film_rgb, film.data(), film.size() * sizeof(float));
+    });
+}
 
 // ------------------------------------------------------------ headless output
 static uint32_t Crc32(const uint8_t *data, size_t n, uint32_t crc) {

@@ -5,6 +5,7 @@
 // cited at each class; glm types are replaced by plain float arrays.
 #pragma once
 #include <cstdint>
+#include <cstring>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -263,5 +264,10 @@ public:
 private:
     pt_ctx *m_ctx;
 };
+
+// Application::Run's offscreen branch (application.cpp:58-76) with progressive images and a film
+// checkpoint; see include/ptamd_host.h for the options.
+void RenderOffscreen(pt_ctx *ctx, Scene &scene, const struct pth_offscreen_options &options, struct pth_offscreen_result &result);
+bool ReadCheckpoint(const std::string &path, int &width, int &height, uint32_t &iterations, std::vector<float> *film);
 
 }  // namespace pth

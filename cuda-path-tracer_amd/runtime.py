@@ -103,6 +103,29 @@ def bvh_build(positions: np.ndarray, indices: np.ndarray, geometries: np.ndarray
         lib.pth_bvh_free(h)
 
 
+def render_offscreen(ctx: "Context", scene: "HostScene", iterations: int = 0, batch: int = 16, save_every: int = 0,
+                     output_prefix: str = None, checkpoint_path: str = None, resume: bool = False) -> dict:
+    """Application::Run's offscreen branch (application.cpp:58-76): progressive PNGs, film checkpoint, resume."""
+    lib = abi.load_library()
+    opt = abi.OffscreenOptions(iterations, batch, save_every, int(resume),
+                               output_prefix.encode() if output_prefix else None,
+                               checkpoint_path.encode() if checkpoint_path else None)
+    res = abi.OffscreenResult()
+    _host_check(lib.pth_render_offscreen(ctx.handle, scene.handle, C.byref(opt), C.byref(res)))
+    return {"first_iteration": res.first_iteration, "iterations_done": res.iterations_done,
+            "images_written": res.images_written, "seconds": res.seconds}
+
+
+def checkpoint_read(path: str):
+    """(film HxWx3 fp32, iterations) of a film checkpoint written by render_offscreen."""
+    lib = abi.load_library()
+    w, h, it = C.c_int(), C.c_int(), C.c_uint32()
+    _host_check(lib.pth_checkpoint_read(path.encode(), C.byref(w), C.byref(h), C.byref(it), None))
+    film = np.zeros((h.value, w.value, 3), np.float32)
+    _host_check(lib.pth_checkpoint_read(path.encode(), C.byref(w), C.byref(h), C.byref(it), abi.vptr(film)))
+    return film, it.value
+
+
 def save_png(path: str, rgba: np.ndarray):
     lib = abi.load_library()
     a = np.ascontiguousarray(rgba, np.uint8)
@@ -366,6 +389,15 @@ class Context:
 
     def film_copy_from_device(self, ptr: int):
         self._check(self._lib.pt_film_copy_from_device(self._h, C.c_void_p(ptr)))
+
+    def film_upload(self, film: np.ndarray):
+        f = np.ascontiguousarray(film, np.float32)
+        self._check(self._lib.pt_film_upload(self._h, abi.vptr(f)))
+
+    def display_download(self, w, h, iterations) -> np.ndarray:
+        out = np.zeros((h, w, 4), np.uint8)
+        self._check(self._lib.pt_display_download(self._h, iterations, abi.vptr(out)))
+        return out
 
     def tonemap(self, film_ptr: int, w, h, iterations, rgba_ptr: int):
         self._check(self._lib.pt_tonemap(self._h, C.c_void_p(film_ptr), w, h, iterations, C.c_void_p(rgba_ptr)))

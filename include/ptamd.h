@@ -320,6 +320,11 @@ int pt_render_batch(pt_ctx *ctx, int width, int height, int iteration, int sampl
 int pt_film_download(pt_ctx *ctx, float *rgb_host);
 int pt_film_copy_to_device(pt_ctx *ctx, float *rgb_device);
 int pt_film_copy_from_device(pt_ctx *ctx, const float *rgb_device);
+/* Restores a film saved with pt_film_download (checkpoint / resume).               */
+int pt_film_upload(pt_ctx *ctx, const float *rgb_host);
+/* The display image of the context's film after `iterations` samples, W*H*4 bytes in HOST memory:
+ * what Application::SaveImage (application.cpp:157-179) copies back before writing the PNG.   */
+int pt_display_download(pt_ctx *ctx, int iterations, uint8_t *rgba_host);
 /* PostprocessAndUpload (path_trace.cu:409-434) on an arbitrary device film:
  * out = quantise(ACES(film / iterations)). film_device NULL = the ctx's film. */
 int pt_tonemap(pt_ctx *ctx, const float *film_device, int width, int height, int iterations,

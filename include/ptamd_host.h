@@ -84,6 +84,32 @@ int pth_integrator_render(pth_integrator *integrator, int width, int height, pth
 int pth_debug_render(pt_ctx *ctx, int width, int height, pth_scene *scene, const pt_integrator_state *state,
                      uint8_t *rgba_device);
 
+/* ---- Application::Run, offscreen branch (application.cpp:58-76), as a library call: renders
+ * iterations [first, scene max or `iterations`) of `scene` on `ctx`, `batch` samples per pass,
+ * and writes <output_prefix>.<n>samp.png every `save_every` iterations (0: only at the end) and at
+ * the end (Application::SaveImage, :157-179; no time stamp in the name).  With a checkpoint path
+ * the film is saved there ("PTFILM1" header, width, height, iterations done, fp32 RGB) at every
+ * save; with `resume` an existing checkpoint of the same size is loaded first and rendering
+ * continues after its last iteration - the film ends up bit-identical to an uninterrupted run.  */
+typedef struct pth_offscreen_options {
+    uint32_t iterations;   /* 0 = the scene's MaxIterations() */
+    uint32_t batch;        /* samples traced per pass (1..1024), 0 = 16 */
+    uint32_t save_every;   /* 0 = only at the end */
+    int32_t resume;
+    const char *output_prefix;    /* NULL = no PNG output */
+    const char *checkpoint_path;  /* NULL = no checkpoint */
+} pth_offscreen_options;
+typedef struct pth_offscreen_result {
+    uint32_t first_iteration;  /* where rendering started (non-zero after a resume) */
+    uint32_t iterations_done;  /* total samples in the film */
+    uint32_t images_written;
+    double seconds;            /* render time, saves excluded */
+} pth_offscreen_result;
+int pth_render_offscreen(pt_ctx *ctx, pth_scene *scene, const pth_offscreen_options *options,
+                         pth_offscreen_result *result);
+/* Reads a checkpoint's header (and, when film_rgb is not NULL, its W*H*3 floats). */
+int pth_checkpoint_read(const char *path, int *width, int *height, uint32_t *iterations, float *film_rgb);
+
 /* ---- headless output replacing the display path (application.cpp:157-179, image.cpp:105-139):
  * writes an 8-bit RGB PNG (stored-deflate) or a Radiance .hdr of a fp32 film / iterations. */
 int pth_save_png(const char *path, const uint8_t *rgba, int width, int height);

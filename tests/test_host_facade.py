@@ -255,3 +255,19 @@ def test_png_and_hdr_writers(pt, tmp_path):
     dec = body[..., :3].astype(np.float64) * (2.0 ** (body[..., 3:4].astype(np.float64) - 136.0))
     ref = film.astype(np.float64) / 2
     assert (np.abs(dec - ref) <= ref.max(axis=2, keepdims=True) / 128).all()  # 8-bit mantissa, shared exponent
+
+
+def test_checkpoint_reader_rejects_foreign_files(pt, tmp_path):
+    p = tmp_path / "x.film"
+    with pytest.raises(pt.PtError, match="no checkpoint"):
+        pt.checkpoint_read(str(p))
+    p.write_bytes(b"PTFILM1\0" + b"\0" * 4)
+    with pytest.raises(pt.PtError, match="not a film checkpoint"):
+        pt.checkpoint_read(str(p))
+    import struct
+    p.write_bytes(b"PTFILM1\0" + struct.pack("<iiII", 2, 1, 7, 0) + np.arange(6, dtype=np.float32).tobytes())
+    film, it = pt.checkpoint_read(str(p))
+    assert it == 7 and film.shape == (1, 2, 3) and np.array_equal(film.reshape(-1), np.arange(6, dtype=np.float32))
+    p.write_bytes(b"PTFILM1\0" + struct.pack("<iiII", 2, 1, 7, 0) + np.arange(5, dtype=np.float32).tobytes())  # truncated
+    with pytest.raises(pt.PtError, match="not a film checkpoint"):
+        pt.checkpoint_read(str(p))
