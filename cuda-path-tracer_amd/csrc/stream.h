@@ -18,6 +18,9 @@
 #pragma once
 #include "traverse.h"
 
+#ifndef PT_STRAIGHT_PUSH
+#define PT_STRAIGHT_PUSH 1
+#endif
 #ifndef PT_POSTPONE_LEAVES
 #define PT_POSTPONE_LEAVES 0  // 1: lanes set leaves aside and keep testing boxes (see Traversal::kPostpone)
 #endif
@@ -94,13 +97,14 @@ struct Traversal {
     static constexpr bool kPostpone = PT_POSTPONE_LEAVES && !COUNT;
     PTD bool leaf_pending() const { return in_blas && (tri_left != 0 || held != kNoRef); }
     PTD bool wants_interior() const { return cur < kNoRef; }
-    PTD bool wants_triangle() const { return in_blas && (cur > kNoRef || tri_left != 0 || held != kNoRef); }
-    PTD bool must_triangle() const { return in_blas && (kPostpone ? (cur > kNoRef && held != kNoRef) : (cur > kNoRef || tri_left != 0)); }
     PTD bool wants_enter() const { return cur > kNoRef && !in_blas; }
-    PTD bool may_pop() const { return cur == kNoRef && sp != base && (kPostpone || !leaf_pending()); }
+    // Without postponement cur keeps naming the leaf until its last triangle is done, so "cur is
+    // empty" alone says that no leaf is waiting.
+    PTD bool wants_triangle() const { return in_blas && (cur > kNoRef || (kPostpone && (tri_left != 0 || held != kNoRef))); }
+    PTD bool may_pop() const { return cur == kNoRef && sp != base; }
     PTD bool wants_pop() const { return may_pop() && sp <= kLdsDepth; }
     PTD bool wants_deep_pop() const { return may_pop() && sp > kLdsDepth; }  // entry is in the global spill area
-    PTD bool wants_level() const { return cur == kNoRef && sp == base && !leaf_pending(); }
+    PTD bool wants_level() const { return cur == kNoRef && sp == base && !(kPostpone && leaf_pending()); }
     // cur is a leaf and `held` is free: set the leaf aside so that the lane can pop on
     PTD void set_leaf_aside() {
         if (kPostpone && in_blas && cur > kNoRef && held == kNoRef) {
@@ -137,6 +141,22 @@ struct Traversal {
         const int depth = sp - base;
         const bool both = hl && hr;
         const bool left_first = tl < tr;
+#if PT_STRAIGHT_PUSH
+        // Usual case, decided for the wave as a whole: no lane is near the reference's 64-entry limit
+        // or the end of the LDS part of the stack.  Then the push is straight-line code: the far
+        // child is written above the top of the stack unconditionally and only counted when both
+        // children were hit.
+        const bool rare = depth >= kRefStack - 1 || sp >= kLdsDepth;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) == 0, 1)) {
+            const uint32_t far_ref = left_first ? rref : lref;
+            const float far_t = left_first ? tr : tl;
+            stk.lds[sp * kWave] = ((unsigned long long)as_u(far_t) << 32) | far_ref;
+            sp += both ? 1 : 0;
+            const uint32_t near_ref = both ? (left_first ? lref : rref) : (hl ? lref : rref);
+            cur = (hl || hr) ? near_ref : kNoRef;
+            return;
+        }
+#endif
         if (__builtin_expect(depth < kRefStack - 1, 1)) {
             if (both) {
                 stack_store(stk, sp, left_first ? rref : lref, left_first ? tr : tl, ev);
@@ -196,13 +216,14 @@ struct Traversal {
     PTD bool op_triangle(const DScene &S) {
         if (tri_left == 0) {  // open the oldest waiting leaf
             if (COUNT) ctr.blas_leaves++;
-            uint32_t leaf;
-            if (held != kNoRef) {
-                leaf = held;
-                held = kNoRef;
-            } else {
-                leaf = cur;
-                cur = kNoRef;
+            uint32_t leaf = cur;
+            if (kPostpone) {  // the leaf leaves the queue now; otherwise cur names it until it is done
+                if (held != kNoRef) {
+                    leaf = held;
+                    held = kNoRef;
+                } else {
+                    cur = kNoRef;
+                }
             }
             tri_next = leaf & 0x0FFFFFFFu;
             tri_left = ((leaf >> 28) & 7u) + 1u;
@@ -230,6 +251,7 @@ struct Traversal {
         }
         ++tri_next;
         --tri_left;
+        if (!kPostpone && tri_left == 0) cur = kNoRef;
         return false;
     }
 
@@ -348,6 +370,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, con
 
         // ---- box-test rounds, while enough lanes take part.  The node loads are issued before
         // the pops so that the LDS round trip hides behind them.
+        const unsigned long long active_mask = __builtin_amdgcn_ballot_w64(active);
         for (;;) {
             if (active) tr.set_leaf_aside();
 #ifdef PT_POP_FIRST
@@ -356,8 +379,9 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, con
                 tr.pop(stk);
             }
 #endif
+            const unsigned long long int_mask = __builtin_amdgcn_ballot_w64(tr.wants_interior()) & active_mask;
             const bool w_int = active && tr.wants_interior();
-            const bool go = count_lanes(w_int) >= PT_VOTE_INT;
+            const bool go = __builtin_popcountll(int_mask) >= PT_VOTE_INT;
             float4 na, nb, nc, nd;
             if (go && w_int) {
                 const float4 *np = reinterpret_cast<const float4 *>(node_base + size_t(tr.cur << 6));
