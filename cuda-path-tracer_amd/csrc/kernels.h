@@ -12,8 +12,12 @@
 
 namespace ptd {
 
-constexpr int kStageFlush = 128;               // a class's staged slots are written out 128 at a time
-constexpr int kStageCap = kStageFlush + 64;    // per-class staging entries per wave: < 128 carried over + <= 64 new
+#ifndef PT_STAGE_FLUSH
+#define PT_STAGE_FLUSH 64
+#endif
+constexpr int kStageFlush = PT_STAGE_FLUSH;       // a class's staged slots are written out this many at a time
+static_assert(kStageFlush >= 64 && kStageFlush % 64 == 0, "whole waves are flushed");
+constexpr int kStageCap = kStageFlush + 64;    // per-class staging entries per wave: < kStageFlush carried over + <= 64 new
 constexpr int kNumClasses = 5;  // 0 = emissive hit or miss, 1 lambertian, 2 mirror, 3 metallic-roughness, 4 dielectric
 
 // Per-bounce counters, 64 B, zeroed once per iteration for all bounces.
@@ -374,7 +378,13 @@ __global__ __launch_bounds__(64) void k_extend(DScene S, PathState P, BounceCoun
 // Same-address atomics serialise at ~12 ns each, so a wave takes kShadeGroup chunks of 64 paths
 // per work fetch when the queues are long, stages the slots it emits (next bounce's extension
 // rays, shadow rays) in LDS and appends them with one atomic per queue and group.
-constexpr uint32_t kShadeGroup = 8;
+#ifndef PT_SHADE_GROUP
+#define PT_SHADE_GROUP 16
+#endif
+#ifndef PT_SHADE_STATIC
+#define PT_SHADE_STATIC 0
+#endif
+constexpr uint32_t kShadeGroup = PT_SHADE_GROUP;
 
 // Diagnostic build only (-DPT_PHASE_PROF -DPT_SHADE_STAMPS): wave clock spent between the marked
 // points of k_shade, every stamp first waiting for all outstanding memory operations.
@@ -411,10 +421,17 @@ __global__ __launch_bounds__(64) void k_shade(DScene S, PathState P, BounceCount
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
 #endif
+#if PT_SHADE_STATIC
+    for (uint32_t round = 0;; ++round) {
+      PT_STAMP(7);
+      const uint32_t first_chunk = (round * gridDim.x + blockIdx.x) * group;  // shading a chunk costs about the same everywhere
+      if (first_chunk >= total_chunks) break;
+#else
     for (;;) {
       PT_STAMP(7);
       const uint32_t first_chunk = wave_fetch(&bc->cur_shade, group);
       if (first_chunk >= total_chunks) break;
+#endif
       const uint32_t end_chunk = (total_chunks - first_chunk < group) ? total_chunks : first_chunk + group;
       uint32_t n_ext = 0, n_sh = 0;  // wave-uniform fill levels of the staging areas
       for (uint32_t chunk = first_chunk; chunk < end_chunk; ++chunk) {

@@ -15,7 +15,22 @@
 #include "debug_view.h"
 #include "bvh_build.h"
 #ifndef PT_WAVES_PER_CU
-#define PT_WAVES_PER_CU 16  // persistent waves per CU (4 per SIMD)
+#define PT_WAVES_PER_CU 16  // persistent waves per CU (4 per SIMD) of a ray query
+#endif
+// The same for the kernels of a render pass, two of which run side by side.  k_shade, whose waves
+// mostly wait for gathers and for the queue counters, does best with few waves (measured: 1065 spp/s
+// with 16 / 16 / 16, 1295 with 10 / 2 / 10 and 1024 paths per queue fetch).
+#ifndef PT_LANES
+#define PT_LANES 2  // render passes in flight (each with its own stream, path state, counters and spill area)
+#endif
+#ifndef PT_EXTEND_WAVES_PER_CU
+#define PT_EXTEND_WAVES_PER_CU 10
+#endif
+#ifndef PT_SHADE_WAVES_PER_CU
+#define PT_SHADE_WAVES_PER_CU 2
+#endif
+#ifndef PT_SHADOW_WAVES_PER_CU
+#define PT_SHADOW_WAVES_PER_CU 10
 #endif
 
 using namespace ptd;
@@ -39,6 +54,7 @@ struct pt_ctx {
     std::string error;
     int num_cus = 256;
     uint32_t grid_blocks = 0;  // persistent grid size (blocks of one wave)
+    uint32_t render_blocks[3] = {0, 0, 0};  // grids of k_extend / k_shade / k_shadow inside a render pass
 
     // scene
     bool scene_ready = false;
@@ -64,7 +80,7 @@ struct pt_ctx {
         uint2 *spill = nullptr;          // traversal-stack spill area of this lane's kernels
         hipEvent_t done = nullptr;       // recorded after the lane's last film pass
         bool pending = false;            // `done` has been recorded and not yet joined
-    } lane[2];
+    } lane[PT_LANES];
     int cur_lane = 0;            // the lane of the last render
     bool overlap_passes = true;  // off while profiling (events bracket kernels on one stream)
     hipEvent_t fork_event = nullptr;
@@ -387,6 +403,15 @@ int pt_ctx_create(int device, pt_ctx **out) {
     int waves_per_cu = std::min(PT_WAVES_PER_CU, int((160 * 1024) / (kLdsDepth * kWave * sizeof(uint2))));
     if (const char *e = getenv("PTAMD_WAVES_PER_CU")) waves_per_cu = std::max(1, std::min(32, atoi(e)));  // tuning aid
     ctx->grid_blocks = uint32_t(ctx->num_cus * waves_per_cu);
+    // Two render passes run side by side, so each pass's kernels take a smaller share of a CU than a
+    // lone query does.
+    static const char *const kRenderEnv[3] = {"PTAMD_EXTEND_WAVES_PER_CU", "PTAMD_SHADE_WAVES_PER_CU", "PTAMD_SHADOW_WAVES_PER_CU"};
+    static const int kRenderWaves[3] = {PT_EXTEND_WAVES_PER_CU, PT_SHADE_WAVES_PER_CU, PT_SHADOW_WAVES_PER_CU};
+    for (int k = 0; k < 3; ++k) {
+        int w = std::min(kRenderWaves[k], waves_per_cu);
+        if (const char *e = getenv(kRenderEnv[k])) w = std::max(1, std::min(waves_per_cu, atoi(e)));  // tuning aid
+        ctx->render_blocks[k] = uint32_t(ctx->num_cus * w);
+    }
     e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete ctx;
@@ -962,22 +987,23 @@ static int RunBounces(pt_ctx *ctx, pt_ctx::Lane &l, hipStream_t stream, int widt
         ScopedEvent ev(timed ? ctx : nullptr, EV_GENERATE);
         hipLaunchKernelGGL(k_generate, dim3(tiles), dim3(kWave), 0, stream, S, P, l.counters, iteration, width, height);
     }
-    const dim3 grid(ctx->grid_blocks), block(kWave);
+    const dim3 block(kWave);
+    const dim3 grid_extend(ctx->render_blocks[0]), grid_shade(ctx->render_blocks[1]), grid_shadow(ctx->render_blocks[2]);
     ctx->last_render_bounces = bounces;
     for (int b = 0; b < bounces; ++b) {
         const bool last = (b == bounces - 1);
         if (last && !shade_last) break;
         {
             ScopedEvent ev(timed ? ctx : nullptr, EV_CLOSEST);
-            hipLaunchKernelGGL(k_extend, grid, block, 0, stream, S, P, l.counters, b, width, height, l.spill, ctx->spill_stride, ctx->dev_stats);
+            hipLaunchKernelGGL(k_extend, grid_extend, block, 0, stream, S, P, l.counters, b, width, height, l.spill, ctx->spill_stride, ctx->dev_stats);
         }
         {
             ScopedEvent ev(timed ? ctx : nullptr, EV_SHADE);
-            hipLaunchKernelGGL(k_shade, grid, block, 0, stream, S, P, l.counters, b);
+            hipLaunchKernelGGL(k_shade, grid_shade, block, 0, stream, S, P, l.counters, b);
         }
         {
             ScopedEvent ev(timed ? ctx : nullptr, EV_ANY);
-            hipLaunchKernelGGL(k_shadow, grid, block, 0, stream, S, P, l.counters, b, l.spill, ctx->spill_stride, ctx->dev_stats);
+            hipLaunchKernelGGL(k_shadow, grid_shadow, block, 0, stream, S, P, l.counters, b, l.spill, ctx->spill_stride, ctx->dev_stats);
         }
         // long depth limits: stop launching once the extension queue has drained
         if ((b & 7) == 7 && b + 1 < bounces) {
@@ -1007,8 +1033,8 @@ int pt_render_batch(pt_ctx *ctx, int width, int height, int iteration, int sampl
     // starts after everything submitted to ctx->stream so far, shares nothing mutable with the
     // pass on the other lane except the film, and takes its turn at the film after that pass.
     const bool overlap = ctx->overlap_passes && !ctx->profiling;
-    const int li = overlap ? (ctx->cur_lane ^ 1) : 0;
-    pt_ctx::Lane &l = ctx->lane[li], &other = ctx->lane[li ^ 1];
+    const int li = overlap ? (ctx->cur_lane + 1) % PT_LANES : 0;
+    pt_ctx::Lane &l = ctx->lane[li], &other = ctx->lane[ctx->cur_lane];  // `other` ran the previous pass
     hipStream_t stream = ctx->stream;
     if (overlap) {
         stream = l.stream;
