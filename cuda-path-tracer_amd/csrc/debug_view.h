@@ -154,8 +154,8 @@ __global__ __launch_bounds__(64) void k_debug_view(DScene S, DebugParams p, floa
                                                    uint32_t spill_stride, DevStats *stats) {
     LaneEvents ev;
     DebugIO io{S, p, image, rgba};
-    __shared__ unsigned long long lds[kLdsDepth * kWave];
-    const LaneStack stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
+    __shared__ unsigned long long lds[kWaveLdsEntries];
+    const auto stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
     trace_stream<MODE_CLOSEST, true>(S, io, n, cursor, stk, ev);
     flush_events(stats, ev);
 }

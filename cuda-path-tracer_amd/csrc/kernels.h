@@ -104,7 +104,8 @@ struct ClosestIO {
         tmax = rd.w;
         return true;
     }
-    PTD void done(uint32_t i, const Traversal<MODE_CLOSEST, COUNT> &tr, bool hit) const {
+    template <class TR>
+    PTD void done(uint32_t i, const TR &tr, bool hit) const {
         int prim = -1, mat = -1;
         if (hit) {
             prim = int(as_u(reinterpret_cast<const float4 *>(S.tris + tr.hit.rec)[2].y));
@@ -125,8 +126,8 @@ __global__ __launch_bounds__(64) void k_trace_closest(DScene S, const pt_ray *ra
                                                       uint2 *spill, uint32_t spill_stride, DevStats *stats, TraceCounters *counters) {
     LaneEvents ev;
     ClosestIO<COUNT> io{S, rays, hits, counters};
-    __shared__ unsigned long long lds[kLdsDepth * kWave];
-    const LaneStack stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
+    __shared__ unsigned long long lds[kWaveLdsEntries];
+    const auto stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
     trace_stream<MODE_CLOSEST, COUNT>(S, io, n, cursor, stk, ev);
     flush_events(stats, ev);
 }
@@ -142,7 +143,8 @@ struct AnyIO {
         tmax = rd.w;
         return true;
     }
-    PTD void done(uint32_t i, const Traversal<MODE_ANY, false> &, bool hit) const { occluded[i] = hit ? 1 : 0; }
+    template <class TR>
+    PTD void done(uint32_t i, const TR &, bool hit) const { occluded[i] = hit ? 1 : 0; }
     PTD bool has_pending() const { return false; }
     PTD void flush() const {}
     PTD void finish() const {}
@@ -152,8 +154,8 @@ __global__ __launch_bounds__(64) void k_trace_any(DScene S, const pt_ray *rays, 
                                                   uint2 *spill, uint32_t spill_stride, DevStats *stats) {
     LaneEvents ev;
     AnyIO io{rays, occluded};
-    __shared__ unsigned long long lds[kLdsDepth * kWave];
-    const LaneStack stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
+    __shared__ unsigned long long lds[kWaveLdsEntries];
+    const auto stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
     trace_stream<MODE_ANY, false>(S, io, n, cursor, stk, ev);
     flush_events(stats, ev);
 }
@@ -291,7 +293,8 @@ struct ExtendIO {
         return true;
     }
     PTD bool has_pending() const { return pending; }
-    PTD void done(uint32_t i, const Traversal<MODE_CLOSEST, false> &tr, bool hit) {
+    template <class TR>
+    PTD void done(uint32_t i, const TR &tr, bool hit) {
         const uint32_t slot = queue ? queue[i] : i;  // a lane may trace several rays at once: nothing is kept from load()
         P.hit_inst[slot] = hit ? tr.hit.inst : -1;
         if (!hit) {
@@ -364,8 +367,8 @@ __global__ __launch_bounds__(64) void k_extend(DScene S, PathState P, BounceCoun
     __shared__ uint32_t stage[kNumClasses * kStageCap];
     ExtendIO io{S, P, bc, bounce == 0 ? nullptr : P.ext_q[bounce & 1], width, height};
     io.stage = stage;
-    __shared__ unsigned long long lds[kLdsDepth * kWave];
-    const LaneStack stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
+    __shared__ unsigned long long lds[wave_lds_entries<kRenderLdsDepth>()];
+    const auto stk = make_lane_stack<kRenderLdsDepth>(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
     trace_stream<MODE_CLOSEST, false>(S, io, bc->ext_count, &bc->cur_extend, stk, ev);
     flush_events(stats, ev);
 }
@@ -725,7 +728,8 @@ struct ShadowIO {
         tmax = so.w;
         return true;
     }
-    PTD void done(uint32_t i, const Traversal<MODE_ANY, false> &, bool occluded) const {
+    template <class TR>
+    PTD void done(uint32_t i, const TR &, bool occluded) const {
         if (occluded) return;
         const uint32_t slot = P.sh_q[i];
         const float4 contrib = P.sh_c[slot];
@@ -745,8 +749,8 @@ __global__ __launch_bounds__(64) void k_shadow(DScene S, PathState P, BounceCoun
     BounceCounters *bc = cnt + bounce;
     LaneEvents ev;
     ShadowIO io{P};
-    __shared__ unsigned long long lds[kLdsDepth * kWave];
-    const LaneStack stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
+    __shared__ unsigned long long lds[wave_lds_entries<kRenderLdsDepth>()];
+    const auto stk = make_lane_stack<kRenderLdsDepth>(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
     trace_stream<MODE_ANY, false>(S, io, bc->shadow_count, &bc->cur_shadow, stk, ev);
     flush_events(stats, ev);
 }

@@ -18,6 +18,9 @@
 #pragma once
 #include "traverse.h"
 
+#ifndef PT_STAGE_RAYS
+#define PT_STAGE_RAYS 1
+#endif
 #ifndef PT_STRAIGHT_PUSH
 #define PT_STRAIGHT_PUSH 1
 #endif
@@ -27,7 +30,7 @@
 
 namespace ptd {
 
-template <int MODE, bool COUNT>
+template <int MODE, bool COUNT, int DEPTH = kLdsDepth>
 struct Traversal {
     V3 o, d, iw;     // world-space ray and reciprocal direction
     V3 co, cd, ci;   // ray in the current space (world, or the current instance's object space)
@@ -102,8 +105,8 @@ struct Traversal {
     // empty" alone says that no leaf is waiting.
     PTD bool wants_triangle() const { return in_blas && (cur > kNoRef || (kPostpone && (tri_left != 0 || held != kNoRef))); }
     PTD bool may_pop() const { return cur == kNoRef && sp != base; }
-    PTD bool wants_pop() const { return may_pop() && sp <= kLdsDepth; }
-    PTD bool wants_deep_pop() const { return may_pop() && sp > kLdsDepth; }  // entry is in the global spill area
+    PTD bool wants_pop() const { return may_pop() && sp <= DEPTH; }
+    PTD bool wants_deep_pop() const { return may_pop() && sp > DEPTH; }  // entry is in the global spill area
     PTD bool wants_level() const { return cur == kNoRef && sp == base && !(kPostpone && leaf_pending()); }
     // cur is a leaf and `held` is free: set the leaf aside so that the lane can pop on
     PTD void set_leaf_aside() {
@@ -116,12 +119,14 @@ struct Traversal {
     // One pop (kernel/intersection.h:54-60): the entry is dropped when its box starts beyond
     // the current bound; then cur stays empty and the lane pops again next round.
     // pop() only touches LDS, so the box-test loop never waits for a global load in it.
-    PTD void pop(const LaneStack &stk) {
+    template <class STK>
+    PTD void pop(const STK &stk) {
         --sp;
         const unsigned long long v = stk.lds[sp * kWave];
         if (MODE == MODE_ANY || as_f(uint32_t(v >> 32)) < cbest) cur = uint32_t(v);
     }
-    PTD void deep_pop(const LaneStack &stk) {
+    template <class STK>
+    PTD void deep_pop(const STK &stk) {
         --sp;
         const uint2 e = stack_load(stk, sp);
         if (MODE == MODE_ANY || as_f(e.y) < cbest) cur = e.x;
@@ -129,7 +134,8 @@ struct Traversal {
 
     // One interior node: both child boxes, near child next, far child pushed
     // (kernel/intersection.h:114-135, :203-226).
-    PTD void op_interior(const LaneStack &stk, LaneEvents &ev, float4 na, float4 nb, float4 nc, float4 nd) {
+    template <class STK>
+    PTD void op_interior(const STK &stk, LaneEvents &ev, float4 na, float4 nb, float4 nc, float4 nd) {
         if (COUNT) {
             ctr.interior++;
             if (!in_blas) tlas_interior++;
@@ -146,7 +152,7 @@ struct Traversal {
         // or the end of the LDS part of the stack.  Then the push is straight-line code: the far
         // child is written above the top of the stack unconditionally and only counted when both
         // children were hit.
-        const bool rare = depth >= kRefStack - 1 || sp >= kLdsDepth;
+        const bool rare = depth >= kRefStack - 1 || sp >= DEPTH;
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) == 0, 1)) {
             const uint32_t far_ref = left_first ? rref : lref;
             const float far_t = left_first ? tr : tl;
@@ -315,9 +321,9 @@ constexpr int kRefillMin = PT_REFILL_MIN;
 // Lanes of the wave for which `pred` holds (the predicate's lane mask is counted directly).
 PTD int count_lanes(bool pred) { return __builtin_popcountll(__builtin_amdgcn_ballot_w64(pred)); }
 
-template <int MODE, bool COUNT, class IO>
-PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, const LaneStack &stk, LaneEvents &ev) {
-    Traversal<MODE, COUNT> tr;
+template <int MODE, bool COUNT, class IO, class STK>
+PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, const STK &stk, LaneEvents &ev) {
+    Traversal<MODE, COUNT, STK::kDepth> tr;
     tr.cur = kNoRef;
     tr.in_blas = false;
     tr.sp = tr.base = 0;
@@ -330,6 +336,66 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, con
     const uint32_t chunk = (n > kFetchChunk * 8u * gridDim.x) ? 4u * kFetchChunk
                            : (n > kFetchChunk * 2u * gridDim.x) ? kFetchChunk : uint32_t(kWave);
     const char *node_base = reinterpret_cast<const char *>(S.nodes);
+#if PT_STAGE_RAYS
+    // Rays are read 64 at a time, by all lanes together, into the wave's LDS, and handed to lanes as
+    // they fall idle: the wave then waits for a gather from path state (thousands of cycles when the
+    // state does not fit the caches) once per 64 rays instead of at every refill.
+    uint32_t stage_base = 0, stage_next = 0, stage_end = 0;  // wave-uniform: staged rays are stream entries stage_base + [stage_next, stage_end)
+    const uint32_t lane_id = threadIdx.x & 63u;
+    for (;;) {
+        int idle = count_lanes(!active);
+        if (idle >= kRefillMin || idle == kWave) {
+            io.flush();
+            for (;;) {
+                if (stage_next == stage_end) {  // restock
+                    if (pool_next >= pool_end && !exhausted) {
+                        uint32_t b = 0;
+                        if (lane_id == 0) b = atomicAdd(cursor, chunk);
+                        b = __shfl(b, 0, 64);
+                        if (b >= n) {
+                            exhausted = true;
+                        } else {
+                            pool_next = b;
+                            pool_end = (n - b < chunk) ? n : b + chunk;
+                        }
+                    }
+                    if (pool_next >= pool_end) break;
+                    const uint32_t count = (pool_end - pool_next < uint32_t(kWave)) ? pool_end - pool_next : uint32_t(kWave);
+                    V3 o = mk3(0.0f, 0.0f, 0.0f), d = o;
+                    float tmax = 0.0f;
+                    bool valid = false;
+                    if (lane_id < count) valid = io.load(pool_next + lane_id, o, d, tmax);  // false: an unused slot of the stream
+                    stk.stage[lane_id] = v4f{o.x, o.y, o.z, tmax};
+                    stk.stage[kWave + lane_id] = v4f{d.x, d.y, d.z, valid ? 1.0f : 0.0f};
+                    __builtin_amdgcn_wave_barrier();
+                    stage_base = pool_next;
+                    stage_next = 0;
+                    stage_end = count;
+                    pool_next += count;
+                }
+                const uint64_t idle_mask = __ballot(!active);
+                const uint32_t prefix = __builtin_amdgcn_mbcnt_hi(uint32_t(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle_mask), 0u));
+                const uint32_t entry = stage_next + prefix;
+                if (!active && entry < stage_end) {
+                    PT_PHASE(ev, 5);
+                    const v4f so = stk.stage[entry], sd = stk.stage[kWave + entry];
+                    if (sd.w != 0.0f) {
+                        ray_index = stage_base + entry;
+                        if (tr.begin(S, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w)) active = true;
+                        else io.done(ray_index, tr, false);
+                    }
+                }
+                const uint32_t wanted = uint32_t(__popcll(idle_mask));
+                stage_next = (stage_end - stage_next < wanted) ? stage_end : stage_next + wanted;
+                if (stage_next < stage_end) break;  // every idle lane was offered a ray
+                idle = count_lanes(!active);
+                if (idle < kRefillMin) break;
+            }
+            if (exhausted && pool_next >= pool_end && stage_next == stage_end && count_lanes(!active) == kWave) break;
+        }
+        const bool can_refill = !(exhausted && pool_next >= pool_end && stage_next == stage_end);  // wave-uniform
+        idle = count_lanes(!active);
+#else
     for (;;) {
         const uint64_t idle_mask = __ballot(!active);
         const int idle = __popcll(idle_mask);
@@ -366,6 +432,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, con
             }
         }
         const bool can_refill = !(exhausted && pool_next >= pool_end);  // wave-uniform
+#endif
         PT_PHASE(ev, 7);
 
         // ---- box-test rounds, while enough lanes take part.  The node loads are issued before

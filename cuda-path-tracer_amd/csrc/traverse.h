@@ -28,9 +28,16 @@ namespace ptd {
 #ifndef PT_LDS_DEPTH
 #define PT_LDS_DEPTH 16
 #endif
-constexpr int kLdsDepth = PT_LDS_DEPTH;  // stack entries per lane held in LDS
+constexpr int kLdsDepth = PT_LDS_DEPTH;  // stack entries per lane held in LDS by the ray-query kernels
+#ifndef PT_RENDER_LDS_DEPTH
+#define PT_RENDER_LDS_DEPTH 8
+#endif
+// The kernels of a render pass share the CUs with the other pass in flight and are sensitive to
+// LDS use (measured: 2 KB more per wave cost 4 % of the frame rate), so they keep fewer entries
+// in LDS and spill a little more often.
+constexpr int kRenderLdsDepth = PT_RENDER_LDS_DEPTH;
 constexpr int kRefStack = 64;  // capacity of each of the reference's two stacks
-constexpr int kSpillDepth = 2 * kRefStack - kLdsDepth;
+constexpr int kSpillDepth = 2 * kRefStack - (kLdsDepth < kRenderLdsDepth ? kLdsDepth : kRenderLdsDepth);  // sized for the shallower LDS part
 constexpr int kWave = 64;
 
 enum { MODE_CLOSEST = 0, MODE_ANY = 1 };
@@ -39,17 +46,30 @@ enum { MODE_CLOSEST = 0, MODE_ANY = 1 };
 // ds_write_b64 and never a flat access that has to pick an address space at run time.
 typedef __attribute__((address_space(3))) unsigned long long *LdsU64;
 
-struct LaneStack {
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4f *LdsF4;
+// A wave's LDS: the stack (kLdsDepth entries for each of 64 lanes) and, behind it, 64 rays read
+// ahead of their use (two float4 each).
+constexpr int kRayStageEntries = 2 * kWave * 2;  // in 8-byte units
+template <int DEPTH>
+constexpr int wave_lds_entries() { return DEPTH * kWave + kRayStageEntries; }
+constexpr int kWaveLdsEntries = wave_lds_entries<kLdsDepth>();
+
+template <int DEPTH>
+struct LaneStackT {
+    static constexpr int kDepth = DEPTH;  // entries per lane in LDS
+    LdsF4 stage;                // the wave's staged rays: (o.xyz, tmax) at [k], (d.xyz, valid) at [64 + k]
     LdsU64 lds;                 // this lane's column of the wave's LDS stack; entry k at lds[k * 64]
     unsigned long long *spill;  // this lane's column of the global spill area; entry k at spill[k * stride]
     uint32_t stride;            // lanes in the spill area
 };
 
-// `lds_array` is the kernel's __shared__ array of kLdsDepth * 64 entries, `spill_base` the wave's
+// `lds_array` is the kernel's __shared__ array of wave_lds_entries<DEPTH>() entries, `spill_base` the wave's
 // first column of the global spill area.
-PTD LaneStack make_lane_stack(unsigned long long *lds_array, uint2 *spill_base, uint32_t stride) {
+template <int DEPTH = kLdsDepth>
+PTD LaneStackT<DEPTH> make_lane_stack(unsigned long long *lds_array, uint2 *spill_base, uint32_t stride) {
     const uint32_t lane = threadIdx.x & 63u;
-    return LaneStack{(LdsU64)(lds_array + lane), reinterpret_cast<unsigned long long *>(spill_base) + lane, stride};
+    return LaneStackT<DEPTH>{(LdsF4)(lds_array + DEPTH * kWave), (LdsU64)(lds_array + lane), reinterpret_cast<unsigned long long *>(spill_base) + lane, stride};
 }
 
 struct HitRec {
@@ -81,21 +101,23 @@ struct LaneEvents {  // rare events, flushed to the context's statistics by the 
 #endif
 
 // One 8-byte record per entry: node reference in the low word, box entry distance in the high.
-PTD void stack_store(const LaneStack &s, int sp, uint32_t ref, float t, LaneEvents &ev) {
+template <class STK>
+PTD void stack_store(const STK &s, int sp, uint32_t ref, float t, LaneEvents &ev) {
     const unsigned long long v = ((unsigned long long)as_u(t) << 32) | ref;
-    if (__builtin_expect(sp < kLdsDepth, 1)) {
+    if (__builtin_expect(sp < STK::kDepth, 1)) {
         s.lds[sp * kWave] = v;
     } else {
-        s.spill[size_t(sp - kLdsDepth) * s.stride] = v;
+        s.spill[size_t(sp - STK::kDepth) * s.stride] = v;
         ev.spills++;
     }
 }
-PTD uint2 stack_load(const LaneStack &s, int sp) {
+template <class STK>
+PTD uint2 stack_load(const STK &s, int sp) {
     unsigned long long v;
-    if (__builtin_expect(sp < kLdsDepth, 1)) {
+    if (__builtin_expect(sp < STK::kDepth, 1)) {
         v = s.lds[sp * kWave];
     } else {
-        v = __builtin_nontemporal_load(s.spill + size_t(sp - kLdsDepth) * s.stride);
+        v = __builtin_nontemporal_load(s.spill + size_t(sp - STK::kDepth) * s.stride);
     }
     return make_uint2(uint32_t(v), uint32_t(v >> 32));
 }
