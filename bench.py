@@ -140,7 +140,7 @@ def main():
         B = max(1, args.spp_batch)
         passes = max(1, args.spp_steps // B)
         args.spp_steps = passes * B
-        for w_pass in range(2):  # untimed: consecutive passes alternate between two sets of path state
+        for w_pass in range(4):  # untimed: consecutive passes rotate through the library's sets of path state (allocated on first use)
             ctx.render_batch(W, H, w_pass * B, B)
         ctx.synchronize()
         ctx.integrator_reset(W, H)

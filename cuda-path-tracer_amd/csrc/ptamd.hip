@@ -21,7 +21,7 @@
 // mostly wait for gathers and for the queue counters, does best with few waves (measured: 1065 spp/s
 // with 16 / 16 / 16, 1295 with 10 / 2 / 10 and 1024 paths per queue fetch).
 #ifndef PT_LANES
-#define PT_LANES 2  // render passes in flight (each with its own stream, path state, counters and spill area)
+#define PT_LANES 3  // render passes in flight (each with its own stream, path state, counters and spill area)
 #endif
 #ifndef PT_EXTEND_WAVES_PER_CU
 #define PT_EXTEND_WAVES_PER_CU 10
