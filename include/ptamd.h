@@ -308,7 +308,7 @@ int pt_render_async(pt_ctx *ctx, int width, int height, int iteration, uint8_t *
  * all their paths are in flight together, so every launch carries `samples` times the work
  * (path state grows to samples * W*H slots; MI355X's HBM is sized for that).  The film receives
  * the samples of a pixel in iteration order, so the result is bit-identical to `samples` calls
- * of pt_render.  Asynchronous like pt_render_async.  Consecutive passes run on two streams of
+ * of pt_render.  Asynchronous like pt_render_async.  Consecutive passes rotate over three streams of
  * the context's own, each starting after the work already submitted to the context's stream;
  * every other entry point makes the context's stream wait for the passes in flight, and
  * pt_synchronize waits for all of them.  No counterpart in the reference, whose Render traces
