@@ -44,9 +44,9 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--capture-iters", type=int, default=8)
-    ap.add_argument("--spp-steps", type=int, default=512, help="render iterations per rank for the spp/s leg (0 = skip)")
-    ap.add_argument("--spp-batch", type=int, default=64,
-                    help="iterations kept in flight per wavefront pass in the spp/s leg (about 0.33 GB of path state per sample at 1080p, two lanes)")
+    ap.add_argument("--spp-steps", type=int, default=1536, help="render iterations per rank for the spp/s leg (0 = skip)")
+    ap.add_argument("--spp-batch", type=int, default=128,
+                    help="iterations kept in flight per wavefront pass in the spp/s leg (about 0.5 GB of path state per sample at 1080p: three passes in flight)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--rays", default="captured", choices=["captured", "synthetic"])
     args = ap.parse_args()

@@ -8,7 +8,7 @@ OUT=gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
 hipcc --offload-arch=gfx950 -O2 -o /tmp/pmc_calib tools/ubench/pmc_calib.hip 2>/dev/null
 BENCH="bench.py --steps 20 --warmup 3 --cpu-seconds 0"
-SHORT="bench.py --steps 3 --warmup 1 --cpu-seconds 0 --spp-steps 8"
+SHORT="bench.py --steps 3 --warmup 1 --cpu-seconds 0 --spp-steps 8 --spp-batch 8"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $BENCH > $OUT/bench_kt.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $SHORT > $OUT/bench_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $SHORT > $OUT/bench_write.log 2>&1
