@@ -65,7 +65,7 @@ struct DebugIO {
     float *image;    // W*H*3, may be null
     uint8_t *rgba;   // W*H*4, may be null
 
-    PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax) const {
+    PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax, uint32_t &) const {
         int x, y;
         if (!slot_to_pixel(i, p.width, p.height, x, y)) return false;
         const DCamera &c = S.camera;  // SpawnCameraRay with sample (0.5, 0.5), kernel/camera.h:10-22
@@ -121,7 +121,7 @@ struct DebugIO {
         return splat(0.0f);
     }
 
-    PTD void done(uint32_t i, const Traversal<MODE_CLOSEST, true> &tr, bool hit) const {
+    PTD void done(uint32_t i, uint32_t, const Traversal<MODE_CLOSEST, true> &tr, bool hit) const {
         int x, y;
         slot_to_pixel(i, p.width, p.height, x, y);
         const size_t index = size_t(x) + size_t(p.width) * size_t(y);

@@ -35,9 +35,11 @@ struct DevStats {
 
 // Per-path state, one array per field, indexed by path slot.  (One 128-byte record per slot was
 // measured too: k_generate's partial-line writes made it 4x slower and k_shade gained nothing.)
+constexpr uint32_t kThroughputNotFinite = 0x80000000u;  // flag in the bounce word of a path's ray
+
 struct PathState {
     float4 *ray_o;     // origin.xyz, last_pdf
-    float4 *ray_d;     // direction.xyz, bits(remaining_bounces)
+    float4 *ray_d;     // direction.xyz, bits(remaining_bounces | kThroughputNotFinite)
     float4 *thr;       // throughput.xyz
     float4 *accum;     // accumulated radiance.xyz
     float4 *last_pos;  // last surface position.xyz
@@ -96,7 +98,7 @@ struct ClosestIO {
     const pt_ray *rays;
     pt_hit *hits;
     TraceCounters *counters;
-    PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax) const {
+    PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax, uint32_t &) const {
         const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
         const float4 ro = rp[0], rd = rp[1];
         o = mk3(ro.x, ro.y, ro.z);
@@ -105,7 +107,7 @@ struct ClosestIO {
         return true;
     }
     template <class TR>
-    PTD void done(uint32_t i, const TR &tr, bool hit) const {
+    PTD void done(uint32_t i, uint32_t, const TR &tr, bool hit) const {
         int prim = -1, mat = -1;
         if (hit) {
             prim = int(as_u(reinterpret_cast<const float4 *>(S.tris + tr.hit.rec)[2].y));
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(64) void k_trace_closest(DScene S, const pt_ray *ra
 struct AnyIO {
     const pt_ray *rays;
     uint8_t *occluded;
-    PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax) const {
+    PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax, uint32_t &) const {
         const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
         const float4 ro = rp[0], rd = rp[1];
         o = mk3(ro.x, ro.y, ro.z);
@@ -144,7 +146,7 @@ struct AnyIO {
         return true;
     }
     template <class TR>
-    PTD void done(uint32_t i, const TR &, bool hit) const { occluded[i] = hit ? 1 : 0; }
+    PTD void done(uint32_t i, uint32_t, const TR &, bool hit) const { occluded[i] = hit ? 1 : 0; }
     PTD bool has_pending() const { return false; }
     PTD void flush() const {}
     PTD void finish() const {}
@@ -277,7 +279,10 @@ struct ExtendIO {
     bool pending = false;
     uint32_t pend_slot = 0;
     int pend_cls = 0;
-    PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax) {
+    // The path slot travels with the ray as its tag.  A throughput that is not finite (flagged in the
+    // bounce word by k_shade) is passed on as t_max = +infinity instead of FLT_MAX: no distance lies
+    // between the two, so the traversal is the same, and done() can tell without reading the path.
+    PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax, uint32_t &tag) {
         uint32_t slot;
         if (queue) {
             slot = queue[i];
@@ -289,18 +294,17 @@ struct ExtendIO {
         const float4 ro = P.ray_o[slot], rd = P.ray_d[slot];
         o = mk3(ro.x, ro.y, ro.z);
         d = mk3(rd.x, rd.y, rd.z);
-        tmax = FLT_MAX;
+        tmax = (as_u(rd.w) & kThroughputNotFinite) ? __builtin_inff() : FLT_MAX;
+        tag = slot;
         return true;
     }
     PTD bool has_pending() const { return pending; }
     template <class TR>
-    PTD void done(uint32_t i, const TR &tr, bool hit) {
-        const uint32_t slot = queue ? queue[i] : i;  // a lane may trace several rays at once: nothing is kept from load()
+    PTD void done(uint32_t, uint32_t slot, const TR &tr, bool hit) {
         P.hit_inst[slot] = hit ? tr.hit.inst : -1;
         if (!hit) {
-            const float4 t = P.thr[slot];
-            const float z = t.x * 0.0f + t.y * 0.0f + t.z * 0.0f;  // NaN iff the throughput is not finite
-            if (z != z) {
+            if (tr.t_max > FLT_MAX) {  // the black environment adds throughput * 0: NaN iff the throughput is not finite
+                const float4 t = P.thr[slot];
                 float4 a = P.accum[slot];
                 a.x += t.x * 0.0f;
                 a.y += t.y * 0.0f;
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(64) void k_shade(DScene S, PathState P, BounceCount
             const float4 ro4 = P.ray_o[slot], rd4 = P.ray_d[slot];
             const V3 ro = mk3(ro4.x, ro4.y, ro4.z), rd = mk3(rd4.x, rd4.y, rd4.z);
             const float last_pdf = ro4.w;
-            int remaining_bounces = int(as_u(rd4.w));
+            int remaining_bounces = int(as_u(rd4.w) & ~kThroughputNotFinite);
             const float4 thr4 = P.thr[slot];
             V3 throughput = mk3(thr4.x, thr4.y, thr4.z);
             const float4 acc4 = P.accum[slot];
@@ -679,7 +683,8 @@ __global__ __launch_bounds__(64) void k_shade(DScene S, PathState P, BounceCount
                 }
                 P.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, 0.0f);
                 P.ray_o[slot] = make_float4(no.x, no.y, no.z, new_last_pdf);
-                P.ray_d[slot] = make_float4(nd.x, nd.y, nd.z, as_f(uint32_t(remaining_bounces)));
+                const float tz = throughput.x * 0.0f + throughput.y * 0.0f + throughput.z * 0.0f;  // NaN iff a component is not finite
+                P.ray_d[slot] = make_float4(nd.x, nd.y, nd.z, as_f(uint32_t(remaining_bounces) | (tz != tz ? kThroughputNotFinite : 0u)));
                 P.rng[slot] = make_uint2(uint32_t(rng), uint32_t(rng >> 32));
             }
         }
@@ -720,8 +725,9 @@ __global__ __launch_bounds__(64) void k_shade(DScene S, PathState P, BounceCount
 // t_max = dist - 1e-4; an unoccluded sample adds its contribution to the path's radiance.
 struct ShadowIO {
     const PathState &P;
-    PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax) {
+    PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax, uint32_t &tag) {
         const uint32_t slot = P.sh_q[i];
+        tag = slot;
         const float4 so = P.sh_o[slot], sd = P.sh_d[slot];
         o = mk3(so.x, so.y, so.z);
         d = mk3(sd.x, sd.y, sd.z);
@@ -729,9 +735,8 @@ struct ShadowIO {
         return true;
     }
     template <class TR>
-    PTD void done(uint32_t i, const TR &, bool occluded) const {
+    PTD void done(uint32_t, uint32_t slot, const TR &, bool occluded) const {
         if (occluded) return;
-        const uint32_t slot = P.sh_q[i];
         const float4 contrib = P.sh_c[slot];
         float4 a = P.accum[slot];
         a.x += contrib.x;

@@ -299,11 +299,12 @@ struct Traversal {
 // from a global cursor, and every lane that finishes its ray takes the next index of the
 // chunk while its neighbours keep traversing (refill happens once at least kRefillMin lanes
 // are idle, so the reload code runs for a meaningful share of the wave).
-//   io.load(i, o, d, tmax)              ray i of the stream
-//   io.done(i, trav, valid)             called once per ray by the lane that traced it
+//   io.load(i, o, d, tmax, tag)         ray i of the stream; tag travels with the ray to done()
+//   io.done(i, tag, trav, valid)        called once per ray by the lane that traced it
 //   io.flush()                          called by all 64 lanes at every refill point
 //   io.finish()                         called by all 64 lanes once, after the last flush
 constexpr uint32_t kFetchChunk = 256;
+constexpr uint32_t kNoRayBits = 0x7FC0DEADu;  // t_max bit pattern (a NaN no computation produces) of a staged entry that holds no ray
 #ifndef PT_REFILL_MIN
 #define PT_REFILL_MIN 12
 #endif
@@ -328,7 +329,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, con
     tr.in_blas = false;
     tr.sp = tr.base = 0;
     bool active = false;
-    uint32_t ray_index = 0;
+    uint32_t ray_index = 0, ray_tag = 0;
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform
     bool exhausted = false;                // wave-uniform
     // rays per work fetch: large for long streams (the cursor is one address, and same-address
@@ -363,10 +364,10 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, con
                     const uint32_t count = (pool_end - pool_next < uint32_t(kWave)) ? pool_end - pool_next : uint32_t(kWave);
                     V3 o = mk3(0.0f, 0.0f, 0.0f), d = o;
                     float tmax = 0.0f;
-                    bool valid = false;
-                    if (lane_id < count) valid = io.load(pool_next + lane_id, o, d, tmax);  // false: an unused slot of the stream
+                    uint32_t tag = 0;
+                    if (lane_id < count && !io.load(pool_next + lane_id, o, d, tmax, tag)) tmax = as_f(kNoRayBits);  // an unused slot of the stream
                     stk.stage[lane_id] = v4f{o.x, o.y, o.z, tmax};
-                    stk.stage[kWave + lane_id] = v4f{d.x, d.y, d.z, valid ? 1.0f : 0.0f};
+                    stk.stage[kWave + lane_id] = v4f{d.x, d.y, d.z, as_f(tag)};
                     __builtin_amdgcn_wave_barrier();
                     stage_base = pool_next;
                     stage_next = 0;
@@ -379,10 +380,11 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, con
                 if (!active && entry < stage_end) {
                     PT_PHASE(ev, 5);
                     const v4f so = stk.stage[entry], sd = stk.stage[kWave + entry];
-                    if (sd.w != 0.0f) {
+                    if (as_u(so.w) != kNoRayBits) {
                         ray_index = stage_base + entry;
+                        ray_tag = as_u(sd.w);
                         if (tr.begin(S, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w)) active = true;
-                        else io.done(ray_index, tr, false);
+                        else io.done(ray_index, ray_tag, tr, false);
                     }
                 }
                 const uint32_t wanted = uint32_t(__popcll(idle_mask));
@@ -419,10 +421,10 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, con
                     PT_PHASE(ev, 5);
                     V3 o, d;
                     float tmax;
-                    if (io.load(mine, o, d, tmax)) {  // false: an unused slot of the stream
+                    if (io.load(mine, o, d, tmax, ray_tag)) {  // false: an unused slot of the stream
                         ray_index = mine;
                         if (tr.begin(S, o, d, tmax)) active = true;
-                        else io.done(ray_index, tr, false);
+                        else io.done(ray_index, ray_tag, tr, false);
                     }
                 }
                 const uint32_t taken = uint32_t(idle);
@@ -495,7 +497,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, con
                     PT_PHASE(ev, 2);
                     if (tr.op_triangle(S)) {  // MODE_ANY only: occluded
                         active = false;
-                        io.done(ray_index, tr, true);
+                        io.done(ray_index, ray_tag, tr, true);
                     }
                 }
                 n_tri = count_lanes(active && tr.wants_triangle());
@@ -513,7 +515,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, con
                 PT_PHASE(ev, 4);
                 if (tr.op_level(S)) {
                     active = false;
-                    io.done(ray_index, tr, MODE == MODE_ANY ? tr.found : tr.closest_valid());
+                    io.done(ray_index, ray_tag, tr, MODE == MODE_ANY ? tr.found : tr.closest_valid());
                 }
             }
         }
