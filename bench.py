@@ -156,10 +156,23 @@ def main():
         barrier()
         spp_elapsed = pt.sharding.max_over_ranks(time.perf_counter() - t0, dev)
         st2 = ctx.stats()
+        # the same leg with trace mode 1 (any-hit searches skip boxes beyond the shadow ray's t_max, which
+        # the reference does not do): reported beside the reference-exact figure, never as `value`
+        ctx.set_trace_mode(1)
+        ctx.integrator_reset(W, H)
+        barrier()
+        t0 = time.perf_counter()
+        for first, count in pt.sharding.iteration_blocks(rank, world, args.spp_steps * world, B):
+            ctx.render_batch(W, H, first, count)
+        ctx.synchronize()
+        barrier()
+        mode1_elapsed = pt.sharding.max_over_ranks(time.perf_counter() - t0, dev)
+        ctx.set_trace_mode(0)
         spp = {"spp_per_s": args.spp_steps * world / spp_elapsed, "ms_per_spp": spp_elapsed * 1e3 / (args.spp_steps * world),
                "mpaths_per_s": args.spp_steps * world * W * H / spp_elapsed / 1e6,
                "rays_last_pass": {"closest": int(st2.closest_rays), "shadow": int(st2.shadow_rays)},
-               "iterations": args.spp_steps * world, "samples_in_flight": B, "film_reduce": "rccl reduce(sum) to rank 0" if distributed else "none"}
+               "iterations": args.spp_steps * world, "samples_in_flight": B,
+               "spp_per_s_trace_mode_1": args.spp_steps * world / mode1_elapsed, "film_reduce": "rccl reduce(sum) to rank 0" if distributed else "none"}
 
     # ---- leg 3: CPU baseline (rank 0, N == 1 only): the oracle's traversal on a bounded sample
     cpu = None

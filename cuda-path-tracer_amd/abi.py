@@ -148,7 +148,7 @@ PT_SYMBOLS = [
     "pt_integrator_init", "pt_integrator_destroy", "pt_integrator_resize", "pt_integrator_reset", "pt_render",
     "pt_render_async", "pt_render_batch", "pt_film_download", "pt_film_copy_to_device", "pt_film_copy_from_device", "pt_film_upload", "pt_display_download", "pt_tonemap",
     "pt_trace_closest", "pt_trace_any", "pt_resolve_hits", "pt_trace_closest_counted", "pt_trace_closest_host",
-    "pt_trace_any_host", "pt_resolve_hits_host", "pt_generate_incoherent_rays", "pt_capture_bounce_rays",
+    "pt_trace_any_host", "pt_resolve_hits_host", "pt_generate_incoherent_rays", "pt_capture_bounce_rays", "pt_capture_shadow_rays",
     "pt_set_trace_mode", "pt_debug_render", "pt_bvh_build", "pt_bvh_sizes", "pt_bvh_get", "pt_bvh_timing", "pt_bvh_free"]
 PTH_SYMBOLS = [
     "pth_last_error", "pth_transform_matrix", "pth_matrix_derive", "pth_matrix_mul", "pth_gltf_local_matrix",
@@ -219,6 +219,7 @@ def load_library() -> C.CDLL:
         "pt_resolve_hits_host": (i32, [vp, vp, vp, sz, vp]),
         "pt_generate_incoherent_rays": (i32, [vp, vp, sz, u64]),
         "pt_capture_bounce_rays": (i32, [vp, i32, i32, i32, i32, vp, sz, C.POINTER(sz)]),
+        "pt_capture_shadow_rays": (i32, [vp, i32, i32, i32, i32, vp, sz, C.POINTER(sz)]),
         "pt_set_trace_mode": (i32, [vp, i32]),
         "pt_bvh_build": (i32, [vp, fp, u32, up, u32, vp, u32, C.POINTER(vp)]),
         "pt_bvh_sizes": (i32, [vp, up, up, up, up]),

@@ -131,6 +131,7 @@ struct DScene {
     uint32_t root_ref;
     float root_min[3], root_max[3];
     uint32_t max_depth;
+    uint32_t any_hit_culls_with_tmax;  // trace mode 1: any-hit searches skip boxes that start beyond the ray's t_max
     float total_light_power;
     DCamera camera;
 };

@@ -823,4 +823,15 @@ __global__ void k_gather_rays(PathState P, const BounceCounters *cnt, int bounce
     rp[1] = make_float4(rd.x, rd.y, rd.z, FLT_MAX);
 }
 
+// Copies the shadow rays of one bounce into a pt_ray buffer (queue order).
+__global__ void k_gather_shadow_rays(PathState P, const BounceCounters *cnt, int bounce, pt_ray *out, uint32_t capacity) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt[bounce].shadow_count || i >= capacity) return;
+    const uint32_t slot = P.sh_q[i];
+    const float4 so = P.sh_o[slot], sd = P.sh_d[slot];
+    float4 *rp = reinterpret_cast<float4 *>(out + i);
+    rp[0] = make_float4(so.x, so.y, so.z, 0.0f);
+    rp[1] = make_float4(sd.x, sd.y, sd.z, so.w);
+}
+
 }  // namespace ptd

@@ -489,8 +489,9 @@ int pt_debug_phase_prof(unsigned long long *out16) {
 
 int pt_set_trace_mode(pt_ctx *ctx, int mode) {
     if (!ctx) return PT_ERR_INVALID;
-    if (mode != 0) return Fail(ctx, PT_ERR_INVALID, "trace mode %d is not available in this build (0 = reference-exact)", mode);
+    if (mode != 0 && mode != 1) return Fail(ctx, PT_ERR_INVALID, "trace mode %d (0 = reference-exact, 1 = any-hit culls boxes with t_max)", mode);
     ctx->trace_mode = mode;
+    ctx->scene.any_hit_culls_with_tmax = mode == 1 ? 1u : 0u;
     return PT_OK;
 }
 
@@ -880,6 +881,7 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
         S.root_max[a] = d->tlas_nodes[0].max[a];
     }
     S.max_depth = d->max_depth;
+    S.any_hit_culls_with_tmax = ctx->trace_mode == 1 ? 1u : 0u;
     S.total_light_power = d->total_light_power;
     FillCamera(S.camera, d->camera);
     ctx->scene_ready = true;
@@ -1305,6 +1307,35 @@ int pt_bvh_timing(const pt_bvh *bvh, float *ms_blas, float *ms_tlas, uint32_t *l
     return PT_OK;
 }
 void pt_bvh_free(pt_bvh *bvh) { delete bvh; }
+
+// The shadow rays (next-event estimation) that the shading of `bounce` emits, with their t_max.
+int pt_capture_shadow_rays(pt_ctx *ctx, int width, int height, int iteration, int bounce, pt_ray *rays_device, size_t capacity, size_t *count) {
+    if (!ctx || !count) return PT_ERR_INVALID;
+    *count = 0;
+    if (!ctx->scene_ready || !ctx->integrator_ready) return Fail(ctx, PT_ERR_STATE, "capture needs an uploaded scene and an initialised integrator");
+    if (width != ctx->width || height != ctx->height) return Fail(ctx, PT_ERR_INVALID, "capture resolution differs from the integrator's");
+    if (bounce < 0 || uint32_t(bounce) >= ctx->scene.max_depth) return Fail(ctx, PT_ERR_INVALID, "bounce %d outside [0, max_depth)", bounce);
+    if (!rays_device || (reinterpret_cast<uintptr_t>(rays_device) & 15u)) return Fail(ctx, PT_ERR_INVALID, "ray buffer must be a 16-byte aligned device pointer");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, Join(ctx));
+    pt_ctx::Lane &l = ctx->lane[0];
+    ctx->cur_lane = 0;
+    int st = RunBounces(ctx, l, ctx->stream, width, height, iteration, 1, bounce + 1, true);
+    ctx->last_render_samples = 1;
+    if (st != PT_OK) return st;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned_word, &l.counters[bounce].shadow_count, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, SyncAll(ctx));
+    const size_t produced = *ctx->pinned_word;
+    if (produced > capacity) return Fail(ctx, PT_ERR_LIMIT, "capture buffer holds %zu rays, %zu needed", capacity, produced);
+    if (produced > 0) {
+        hipLaunchKernelGGL(k_gather_shadow_rays, dim3(uint32_t((produced + 255) / 256)), dim3(256), 0, ctx->stream, l.paths, l.counters, bounce, rays_device,
+                           uint32_t(capacity));
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, SyncAll(ctx));
+    }
+    *count = produced;
+    return PT_OK;
+}
 
 }  // extern "C"
 

@@ -72,7 +72,9 @@ struct Traversal {
         cd = d;
         ci = iw;
         best = FLT_MAX;
-        cbest = (MODE == MODE_ANY) ? t_max : FLT_MAX;
+        // ANY: the reference tests child boxes against "no hit yet" (FLT_MAX), never against the ray's
+        // t_max (kernel/intersection.h:120-121, :209-210); only the scene's root box is (:162)
+        cbest = (MODE == MODE_ANY && S.any_hit_culls_with_tmax) ? t_max : FLT_MAX;
         lrec = 0;
         lu = lv = 0.0f;
         cur_inst = -1;

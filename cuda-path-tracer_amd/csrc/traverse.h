@@ -15,7 +15,10 @@
 //     (utils/stack.h:8-11); the drop order of the reference is reproduced.
 // Differences that do not change results: the near child is kept in a register instead of
 // being pushed and popped again; both levels share one physical stack; ANY returns at the
-// first accepted triangle and culls boxes with the ray's t_max.
+// first accepted triangle.  Like the reference, ANY tests boxes against FLT_MAX, not against the
+// ray's t_max: a box test and a triangle test can disagree within rounding when t is close to
+// t_max (a grazing shadow ray ending on the light it was aimed at), and then skipping the box
+// would change the answer.  Trace mode 1 does skip such boxes.
 //
 // The stack lives in LDS as [entry][lane] 8-byte records: a wave's 64 lanes at any mix of
 // depths hit 64 different bank pairs, so pushes and pops never conflict.  Entries beyond

@@ -347,6 +347,10 @@ class Context:
     def synchronize(self):
         self._check(self._lib.pt_synchronize(self._h))
 
+    def set_trace_mode(self, mode: int):
+        """0 = reference-exact (default); 1 = any-hit searches skip boxes beyond the ray's t_max."""
+        self._check(self._lib.pt_set_trace_mode(self._h, int(mode)))
+
     def set_profiling(self, on: bool):
         self._check(self._lib.pt_set_profiling(self._h, int(on)))
 
@@ -446,6 +450,11 @@ class Context:
     def capture_bounce_rays(self, w, h, iteration, bounce, rays_ptr: int, capacity: int) -> int:
         cnt = C.c_size_t()
         self._check(self._lib.pt_capture_bounce_rays(self._h, w, h, iteration, bounce, C.c_void_p(rays_ptr), capacity, C.byref(cnt)))
+        return cnt.value
+
+    def capture_shadow_rays(self, w, h, iteration, bounce, rays_ptr: int, capacity: int) -> int:
+        cnt = C.c_size_t()
+        self._check(self._lib.pt_capture_shadow_rays(self._h, w, h, iteration, bounce, C.c_void_p(rays_ptr), capacity, C.byref(cnt)))
         return cnt.value
 
     # host-array conveniences

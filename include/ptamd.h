@@ -419,8 +419,15 @@ int pt_generate_incoherent_rays(pt_ctx *ctx, pt_ray *rays_device, size_t n, uint
 int pt_capture_bounce_rays(pt_ctx *ctx, int width, int height, int iteration, int bounce,
                            pt_ray *rays_device, size_t capacity, size_t *count);
 
-/* Traversal variant: 0 = reference-exact ordering (default), 1 = fast
- * (cross-instance culling with the global best t; ids may differ at exact ties). */
+/* Captures the shadow rays (next-event estimation, path_trace.cu:221-243) that the shading of
+ * `bounce` emits in `iteration`, with their t_max = distance - 1e-4, in queue order.          */
+int pt_capture_shadow_rays(pt_ctx *ctx, int width, int height, int iteration, int bounce,
+                           pt_ray *rays_device, size_t capacity, size_t *count);
+
+/* Traversal variant: 0 = reference-exact (default).  1 = any-hit searches (pt_trace_any, shadow
+ * rays) skip boxes that start beyond the ray's t_max, which the reference does not do
+ * (kernel/intersection.h:120-121,209-210 test child boxes against FLT_MAX): fewer nodes are
+ * visited, and the occlusion flag can differ where a triangle lies within rounding of t_max.  */
 int pt_set_trace_mode(pt_ctx *ctx, int mode);
 
 #ifdef __cplusplus

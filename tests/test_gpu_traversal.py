@@ -105,6 +105,37 @@ def test_any_hit_matches_oracle(pt, ora, gpu_ctx, devbuf, scene_factory, tiny_sc
         assert 0.05 < occ.mean() < 0.95
 
 
+def test_any_hit_on_captured_shadow_rays(pt, ora, gpu_ctx, devbuf, scene_factory):
+    """The next-event-estimation rays the shading really emits (t_max = distance to the light sample
+    - 1e-4): the occlusion flags equal the oracle's, and a fair share of both outcomes occurs."""
+    w, h = 96, 96
+    hs = scene_factory("teapot", w, h, 6)
+    desc = _upload_scene(gpu_ctx, hs)
+    gpu_ctx.integrator_init(w, h)
+    buf = devbuf(w * h * 32)
+    total = 0
+    for bounce in (0, 1):
+        n = gpu_ctx.capture_shadow_rays(w, h, 0, bounce, buf.ptr, w * h)
+        assert 0 < n <= w * h
+        rays = buf.download(pt.abi.RAY, n)
+        assert np.isfinite(rays["tmax"]).all() and (rays["tmax"] < 1e6).all()
+        occ = gpu_ctx.trace_any_host(rays)
+        ref = ora.trace_any(desc, rays, nthreads=8)
+        assert np.array_equal(occ, ref)
+        assert 0.02 < occ.mean() < 0.98
+        # trace mode 1 skips boxes beyond t_max: it can only lose occluders whose triangle test lands
+        # within rounding of t_max (grazing rays that end on the light they were aimed at)
+        gpu_ctx.set_trace_mode(1)
+        fast = gpu_ctx.trace_any_host(rays)
+        gpu_ctx.set_trace_mode(0)
+        assert (fast <= ref).all() and (fast != ref).mean() < 0.01
+        total += n
+    # the same rays are what the render traced: one iteration's shadow-ray count covers them
+    gpu_ctx.reset_stats()
+    gpu_ctx.render(w, h, 0)
+    assert gpu_ctx.stats().shadow_rays >= total
+
+
 def test_closest_hit_honours_tmax_and_degenerate_rays(pt, ora, gpu_ctx, scene_factory):
     hs = scene_factory("cornell", 64, 64, 4)
     desc = _upload_scene(gpu_ctx, hs)
