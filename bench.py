@@ -211,7 +211,7 @@ def main():
     if rank == 0:
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         out = {
-            "metric": "Mrays/s incoherent closest-hit (helmet, 1080p captured bounce rays)", "value": mrays, "unit": "Mrays/s",
+            "metric": f"Mrays/s incoherent closest-hit ({args.scene}, {W}x{H} {args.rays} bounce rays)", "value": mrays, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "rays_per_rank": n_rays, "scene": args.scene, "resolution": [W, H], "max_depth": depth,

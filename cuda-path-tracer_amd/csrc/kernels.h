@@ -79,6 +79,13 @@ PTD uint32_t wave_fetch(uint32_t *cursor, uint32_t amount) {
 #ifdef PT_PHASE_PROF
 __device__ unsigned long long g_phase_prof[16];
 #endif
+#ifdef PT_WAVE_TIMES
+// Diagnostic build: start and end of every wave of the last closest-hit query (100 MHz clock).
+__device__ unsigned long long g_wave_times[2 * 8192];
+#define PT_WAVE_TIME(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_wave_times[2 * blockIdx.x + (k)] = wall_clock64(); } while (0)
+#else
+#define PT_WAVE_TIME(k) do { } while (0)
+#endif
 
 PTD void flush_events(DevStats *stats, const LaneEvents &ev) {
     if (ev.spills) atomicAdd(&stats->spills, ev.spills);
@@ -124,13 +131,15 @@ struct ClosestIO {
 };
 
 template <bool COUNT>
-__global__ __launch_bounds__(64) void k_trace_closest(DScene S, const pt_ray *rays, uint32_t n, pt_hit *hits, uint32_t *cursor,
+__global__ __launch_bounds__(64) void k_trace_closest(DScene S, const pt_ray *rays, uint32_t n, pt_hit *hits, uint32_t *cursors, uint32_t cursor_count,
                                                       uint2 *spill, uint32_t spill_stride, DevStats *stats, TraceCounters *counters) {
     LaneEvents ev;
     ClosestIO<COUNT> io{S, rays, hits, counters};
     __shared__ unsigned long long lds[kWaveLdsEntries];
     const auto stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
-    trace_stream<MODE_CLOSEST, COUNT>(S, io, n, cursor, stk, ev);
+    PT_WAVE_TIME(0);
+    trace_stream<MODE_CLOSEST, COUNT>(S, io, n, make_feed(cursors, cursor_count, n), stk, ev);
+    PT_WAVE_TIME(1);
     flush_events(stats, ev);
 }
 
@@ -152,13 +161,13 @@ struct AnyIO {
     PTD void finish() const {}
 };
 
-__global__ __launch_bounds__(64) void k_trace_any(DScene S, const pt_ray *rays, uint32_t n, uint8_t *occluded, uint32_t *cursor,
+__global__ __launch_bounds__(64) void k_trace_any(DScene S, const pt_ray *rays, uint32_t n, uint8_t *occluded, uint32_t *cursors, uint32_t cursor_count,
                                                   uint2 *spill, uint32_t spill_stride, DevStats *stats) {
     LaneEvents ev;
     AnyIO io{rays, occluded};
     __shared__ unsigned long long lds[kWaveLdsEntries];
     const auto stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
-    trace_stream<MODE_ANY, false>(S, io, n, cursor, stk, ev);
+    trace_stream<MODE_ANY, false>(S, io, n, make_feed(cursors, cursor_count, n), stk, ev);
     flush_events(stats, ev);
 }
 
@@ -373,7 +382,7 @@ __global__ __launch_bounds__(64) void k_extend(DScene S, PathState P, BounceCoun
     io.stage = stage;
     __shared__ unsigned long long lds[wave_lds_entries<kRenderLdsDepth>()];
     const auto stk = make_lane_stack<kRenderLdsDepth>(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
-    trace_stream<MODE_CLOSEST, false>(S, io, bc->ext_count, &bc->cur_extend, stk, ev);
+    trace_stream<MODE_CLOSEST, false>(S, io, bc->ext_count, make_feed(&bc->cur_extend, 1u, bc->ext_count), stk, ev);
     flush_events(stats, ev);
 }
 
@@ -756,7 +765,7 @@ __global__ __launch_bounds__(64) void k_shadow(DScene S, PathState P, BounceCoun
     ShadowIO io{P};
     __shared__ unsigned long long lds[wave_lds_entries<kRenderLdsDepth>()];
     const auto stk = make_lane_stack<kRenderLdsDepth>(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
-    trace_stream<MODE_ANY, false>(S, io, bc->shadow_count, &bc->cur_shadow, stk, ev);
+    trace_stream<MODE_ANY, false>(S, io, bc->shadow_count, make_feed(&bc->cur_shadow, 1u, bc->shadow_count), stk, ev);
     flush_events(stats, ev);
 }
 

@@ -32,6 +32,10 @@
 #ifndef PT_SHADOW_WAVES_PER_CU
 #define PT_SHADOW_WAVES_PER_CU 10
 #endif
+#ifndef PT_QUERY_CURSORS
+#define PT_QUERY_CURSORS 8   // work-fetch cursors of a batch query (one per XCD's share of the waves)
+#endif
+constexpr uint32_t kMaxQueryCursors = 64;
 
 using namespace ptd;
 
@@ -63,7 +67,8 @@ struct pt_ctx {
 
     // traversal scratch
     uint32_t spill_stride = 0;
-    uint32_t *cursor = nullptr;  // work-fetch cursor of the batch queries
+    uint32_t *cursor = nullptr;  // work-fetch cursors of the batch queries, kCursorStride words apart
+    uint32_t query_cursors = PT_QUERY_CURSORS;
     DevStats *dev_stats = nullptr;
 
     // integrator.  Everything a render pass mutates besides the film exists twice ("lanes"):
@@ -359,7 +364,7 @@ int EnsureScratch(pt_ctx *ctx) {
     ctx->spill_stride = ctx->grid_blocks * kWave;
     const int st = EnsureLaneSpill(ctx, ctx->lane[0]);
     if (st != PT_OK) return st;
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->cursor), 256));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->cursor), size_t(kMaxQueryCursors) * kCursorStride * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->dev_stats), sizeof(DevStats)));
     HIP_TRY(ctx, hipMemsetAsync(ctx->dev_stats, 0, sizeof(DevStats), ctx->stream));
     HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->pinned_word), 64, hipHostMallocDefault));
@@ -403,6 +408,7 @@ int pt_ctx_create(int device, pt_ctx **out) {
     int waves_per_cu = std::min(PT_WAVES_PER_CU, int((160 * 1024) / (kLdsDepth * kWave * sizeof(uint2))));
     if (const char *e = getenv("PTAMD_WAVES_PER_CU")) waves_per_cu = std::max(1, std::min(32, atoi(e)));  // tuning aid
     ctx->grid_blocks = uint32_t(ctx->num_cus * waves_per_cu);
+    if (const char *e = getenv("PTAMD_QUERY_CURSORS")) ctx->query_cursors = uint32_t(std::max(1, std::min(int(kMaxQueryCursors), atoi(e))));  // tuning aid
     // Two render passes run side by side, so each pass's kernels take a smaller share of a CU than a
     // lone query does.
     static const char *const kRenderEnv[3] = {"PTAMD_EXTEND_WAVES_PER_CU", "PTAMD_SHADE_WAVES_PER_CU", "PTAMD_SHADOW_WAVES_PER_CU"};
@@ -483,6 +489,15 @@ int pt_debug_phase_prof(unsigned long long *out16) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ptd::g_phase_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return PT_ERR_DEVICE;
     unsigned long long zero[16] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_phase_prof), zero, sizeof(zero)) != hipSuccess) return PT_ERR_DEVICE;
+    return PT_OK;
+}
+#endif
+
+#ifdef PT_WAVE_TIMES
+// Diagnostic build only: (start, end) clock pairs of the waves of the last closest-hit query.
+int pt_debug_wave_times(unsigned long long *out, unsigned waves) {
+    if (waves > 8192) return PT_ERR_INVALID;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ptd::g_wave_times), size_t(waves) * 2 * sizeof(unsigned long long)) != hipSuccess) return PT_ERR_DEVICE;
     return PT_OK;
 }
 #endif
@@ -1175,11 +1190,11 @@ int pt_trace_closest(pt_ctx *ctx, const pt_ray *rays, size_t n, pt_hit *hits) {
     if ((reinterpret_cast<uintptr_t>(hits) & 15u) != 0) return Fail(ctx, PT_ERR_INVALID, "hit buffer must be 16-byte aligned");
     DeviceGuard guard(ctx->device);
     HIP_TRY(ctx, Join(ctx));  // lane 0's spill area is shared with render passes
-    HIP_TRY(ctx, hipMemsetAsync(ctx->cursor, 0, sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->cursor, 0, size_t(ctx->query_cursors) * kCursorStride * sizeof(uint32_t), ctx->stream));
     const uint32_t blocks = uint32_t(std::min<size_t>(ctx->grid_blocks, (n + kWave - 1) / kWave));
     {
         ScopedEvent ev(ctx, EV_CLOSEST);
-        hipLaunchKernelGGL(k_trace_closest<false>, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor,
+        hipLaunchKernelGGL(k_trace_closest<false>, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors,
                            ctx->lane[0].spill, ctx->spill_stride, ctx->dev_stats, static_cast<TraceCounters *>(nullptr));
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -1191,11 +1206,11 @@ int pt_trace_any(pt_ctx *ctx, const pt_ray *rays, size_t n, uint8_t *occluded) {
     if (st != PT_OK || n == 0) return st;
     DeviceGuard guard(ctx->device);
     HIP_TRY(ctx, Join(ctx));  // lane 0's spill area is shared with render passes
-    HIP_TRY(ctx, hipMemsetAsync(ctx->cursor, 0, sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->cursor, 0, size_t(ctx->query_cursors) * kCursorStride * sizeof(uint32_t), ctx->stream));
     const uint32_t blocks = uint32_t(std::min<size_t>(ctx->grid_blocks, (n + kWave - 1) / kWave));
     {
         ScopedEvent ev(ctx, EV_ANY);
-        hipLaunchKernelGGL(k_trace_any, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), occluded, ctx->cursor, ctx->lane[0].spill,
+        hipLaunchKernelGGL(k_trace_any, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), occluded, ctx->cursor, ctx->query_cursors, ctx->lane[0].spill,
                            ctx->spill_stride, ctx->dev_stats);
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -1220,9 +1235,9 @@ int pt_trace_closest_counted(pt_ctx *ctx, const pt_ray *rays, size_t n, pt_hit *
     if (!counters4) return Fail(ctx, PT_ERR_INVALID, "null counter buffer");
     DeviceGuard guard(ctx->device);
     HIP_TRY(ctx, Join(ctx));  // lane 0's spill area is shared with render passes
-    HIP_TRY(ctx, hipMemsetAsync(ctx->cursor, 0, sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->cursor, 0, size_t(ctx->query_cursors) * kCursorStride * sizeof(uint32_t), ctx->stream));
     const uint32_t blocks = uint32_t(std::min<size_t>(ctx->grid_blocks, (n + kWave - 1) / kWave));
-    hipLaunchKernelGGL(k_trace_closest<true>, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->lane[0].spill,
+    hipLaunchKernelGGL(k_trace_closest<true>, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors, ctx->lane[0].spill,
                        ctx->spill_stride, ctx->dev_stats, reinterpret_cast<TraceCounters *>(counters4));
     HIP_TRY(ctx, hipGetLastError());
     return PT_OK;
@@ -1249,12 +1264,12 @@ int pt_debug_render(pt_ctx *ctx, int width, int height, const pt_integrator_stat
     if (rgba_device && (reinterpret_cast<uintptr_t>(rgba_device) & 3u) != 0) return Fail(ctx, PT_ERR_INVALID, "rgba buffer must be 4-byte aligned");
     DeviceGuard guard(ctx->device);
     HIP_TRY(ctx, Join(ctx));  // lane 0's spill area is shared with render passes
-    HIP_TRY(ctx, hipMemsetAsync(ctx->cursor, 0, sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->cursor, 0, size_t(ctx->query_cursors) * kCursorStride * sizeof(uint32_t), ctx->stream));
     const uint32_t tiles = (uint32_t(width + 7) >> 3) * (uint32_t(height + 7) >> 3);
     const uint32_t n = tiles * 64u;
     const uint32_t blocks = std::min<uint32_t>(ctx->grid_blocks, tiles);
     const DebugParams p{state->visualize_bvh, state->bvh_visualize_type, state->bvh_visualize_depth, state->debug_mode, width, height};
-    hipLaunchKernelGGL(k_debug_view, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, p, image_device, rgba_device, n, ctx->cursor,
+    hipLaunchKernelGGL(k_debug_view, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, p, image_device, rgba_device, n, ctx->cursor, ctx->query_cursors,
                        ctx->lane[0].spill, ctx->spill_stride, ctx->dev_stats);
     HIP_TRY(ctx, hipGetLastError());
     return PT_OK;

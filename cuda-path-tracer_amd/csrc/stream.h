@@ -297,7 +297,7 @@ struct Traversal {
     }
 };
 
-// Streams `n` rays through a persistent wave: the wave pulls chunks of kFetchChunk ray indices
+// Streams `n` rays through a persistent wave: the wave pulls chunks of ray indices (fetch_rays)
 // from a global cursor, and every lane that finishes its ray takes the next index of the
 // chunk while its neighbours keep traversing (refill happens once at least kRefillMin lanes
 // are idle, so the reload code runs for a meaningful share of the wave).
@@ -316,6 +316,9 @@ constexpr uint32_t kNoRayBits = 0x7FC0DEADu;  // t_max bit pattern (a NaN no com
 #ifndef PT_VOTE_TRI
 #define PT_VOTE_TRI 12   // lanes that keep the triangle loop running
 #endif
+#ifndef PT_DRAIN_ALL_OPS
+#define PT_DRAIN_ALL_OPS 1
+#endif
 #ifndef PT_VOTE_RARE
 #define PT_VOTE_RARE 8   // lanes that make an instance enter / level change round worth running
 #endif
@@ -324,8 +327,46 @@ constexpr int kRefillMin = PT_REFILL_MIN;
 // Lanes of the wave for which `pred` holds (the predicate's lane mask is counted directly).
 PTD int count_lanes(bool pred) { return __builtin_popcountll(__builtin_amdgcn_ballot_w64(pred)); }
 
+// Where a wave gets its rays from.  The stream is cut into chunks of `chunk` rays; chunk number
+// t * groups + g is handed out by ticket t of cursor g.  With one cursor the chunks must be large
+// for long streams, because the cursor is one address and same-address atomics serialise at
+// ~12 ns each; a wave then holds hundreds of neighbouring (similarly expensive) rays when the
+// others run dry.  With several cursors on separate cache lines the chunks are one wave's worth:
+// each cursor serves the waves whose number is congruent to g, its chunks are interleaved with the
+// other cursors' over the whole stream, and a wave whose cursor has run dry goes on to the next.
+#ifndef PT_FEED_CHUNK
+#define PT_FEED_CHUNK 64
+#endif
+constexpr uint32_t kCursorStride = 64;  // words between cursors: 256 bytes
+struct WorkFeed {
+    uint32_t *cursors;
+    uint32_t groups, chunk;
+};
+PTD WorkFeed make_feed(uint32_t *cursors, uint32_t groups, uint32_t n) {
+    if (groups > 1) return WorkFeed{cursors, groups, uint32_t(PT_FEED_CHUNK)};
+    const uint32_t chunk = (n > kFetchChunk * 8u * gridDim.x) ? 4u * kFetchChunk : (n > kFetchChunk * 2u * gridDim.x) ? kFetchChunk : uint32_t(kWave);
+    return WorkFeed{cursors, 1u, chunk};
+}
+// One work fetch: true and [base, end) when the wave got rays.  `dry` counts the cursors the wave
+// has found empty (wave-uniform; the feed is exhausted once dry == groups).  A fetch probes one
+// cursor, so a wave whose other lanes are still traversing waits for one round trip at most.
+PTD bool fetch_rays(const WorkFeed &feed, uint32_t n, uint32_t &dry, uint32_t &base, uint32_t &end) {
+    const uint32_t g = (blockIdx.x + dry) % feed.groups;
+    uint32_t t = 0;
+    if ((threadIdx.x & 63u) == 0) t = atomicAdd(feed.cursors + size_t(g) * kCursorStride, 1u);
+    t = __shfl(t, 0, 64);
+    const unsigned long long first = ((unsigned long long)t * feed.groups + g) * feed.chunk;
+    if (first >= n) {
+        ++dry;
+        return false;
+    }
+    base = uint32_t(first);
+    end = (n - base < feed.chunk) ? n : base + feed.chunk;
+    return true;
+}
+
 template <int MODE, bool COUNT, class IO, class STK>
-PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, const STK &stk, LaneEvents &ev) {
+PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed, const STK &stk, LaneEvents &ev) {
     Traversal<MODE, COUNT, STK::kDepth> tr;
     tr.cur = kNoRef;
     tr.in_blas = false;
@@ -333,11 +374,8 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, con
     bool active = false;
     uint32_t ray_index = 0, ray_tag = 0;
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform
+    uint32_t dry = 0;                      // wave-uniform: cursors found empty
     bool exhausted = false;                // wave-uniform
-    // rays per work fetch: large for long streams (the cursor is one address, and same-address
-    // atomics serialise at ~12 ns each), one wave's worth for short ones (load balance)
-    const uint32_t chunk = (n > kFetchChunk * 8u * gridDim.x) ? 4u * kFetchChunk
-                           : (n > kFetchChunk * 2u * gridDim.x) ? kFetchChunk : uint32_t(kWave);
     const char *node_base = reinterpret_cast<const char *>(S.nodes);
 #if PT_STAGE_RAYS
     // Rays are read 64 at a time, by all lanes together, into the wave's LDS, and handed to lanes as
@@ -352,15 +390,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, con
             for (;;) {
                 if (stage_next == stage_end) {  // restock
                     if (pool_next >= pool_end && !exhausted) {
-                        uint32_t b = 0;
-                        if (lane_id == 0) b = atomicAdd(cursor, chunk);
-                        b = __shfl(b, 0, 64);
-                        if (b >= n) {
-                            exhausted = true;
-                        } else {
-                            pool_next = b;
-                            pool_end = (n - b < chunk) ? n : b + chunk;
-                        }
+                        if (!fetch_rays(feed, n, dry, pool_next, pool_end)) exhausted = dry >= feed.groups;
                     }
                     if (pool_next >= pool_end) break;
                     const uint32_t count = (pool_end - pool_next < uint32_t(kWave)) ? pool_end - pool_next : uint32_t(kWave);
@@ -406,15 +436,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, con
         if (idle >= kRefillMin || idle == kWave) {
             io.flush();
             if (pool_next >= pool_end && !exhausted) {
-                uint32_t b = 0;
-                if ((threadIdx.x & 63) == 0) b = atomicAdd(cursor, chunk);
-                b = __shfl(b, 0, 64);
-                if (b >= n) {
-                    exhausted = true;
-                } else {
-                    pool_next = b;
-                    pool_end = (n - b < chunk) ? n : b + chunk;
-                }
+                if (!fetch_rays(feed, n, dry, pool_next, pool_end)) exhausted = dry >= feed.groups;
             }
             if (pool_next < pool_end) {
                 const uint32_t prefix = __builtin_amdgcn_mbcnt_hi(uint32_t(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle_mask), 0u));
@@ -486,14 +508,18 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, con
         const int n_max = max(max(n_int, n_tri), max(n_ent, n_lvl));
         if (n_max == 0) continue;  // only lanes that are still popping
         if (n_int >= PT_VOTE_INT) continue;  // pops brought the box-test loop back above its threshold
-        if (n_int == n_max) {  // fewer than PT_VOTE_INT lanes, but still the largest group
+        // Once the wave has no rays left to hand out, idle lanes stay idle whatever the others do:
+        // every operation some lane waits for then runs in every round, so that no ray's last steps
+        // are held back by a vote.
+        const bool drain = PT_DRAIN_ALL_OPS && !can_refill;
+        if (n_int == n_max || (drain && n_int > 0)) {  // fewer than PT_VOTE_INT lanes, but still the largest group
             if (w_int) {
                 PT_PHASE(ev, 0);
                 const float4 *np = reinterpret_cast<const float4 *>(node_base + size_t(tr.cur << 6));
                 tr.op_interior(stk, ev, np[0], np[1], np[2], np[3]);
             }
         }
-        if (n_tri >= PT_VOTE_TRI || n_tri == n_max) {
+        if (n_tri >= PT_VOTE_TRI || n_tri == n_max || (drain && n_tri > 0)) {
             do {
                 if (active && tr.wants_triangle()) {
                     PT_PHASE(ev, 2);
@@ -505,13 +531,13 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, uint32_t *cursor, con
                 n_tri = count_lanes(active && tr.wants_triangle());
             } while (n_tri >= PT_VOTE_TRI);
         }
-        if (n_ent > 0 && (n_ent >= PT_VOTE_RARE || n_ent == n_max)) {
+        if (n_ent > 0 && (n_ent >= PT_VOTE_RARE || n_ent == n_max || drain)) {
             if (w_ent) {
                 PT_PHASE(ev, 1);
                 tr.op_enter(S);
             }
         }
-        if (n_lvl > 0 && (n_lvl >= PT_VOTE_RARE || n_lvl == n_max || (can_refill && n_lvl + idle >= kRefillMin))) {
+        if (n_lvl > 0 && (n_lvl >= PT_VOTE_RARE || n_lvl == n_max || drain || (can_refill && n_lvl + idle >= kRefillMin))) {
             if (w_deep) tr.deep_pop(stk);
             if (w_lvl) {
                 PT_PHASE(ev, 4);
