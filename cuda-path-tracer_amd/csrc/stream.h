@@ -464,6 +464,8 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
         // ---- box-test rounds, while enough lanes take part.  The node loads are issued before
         // the pops so that the LDS round trip hides behind them.
         const unsigned long long active_mask = __builtin_amdgcn_ballot_w64(active);
+        // a wave that can no longer refill keeps the loop going for half of the lanes it has left
+        const int vote_int = (PT_DRAIN_ALL_OPS && !can_refill) ? max(1, (__builtin_popcountll(active_mask) + 1) >> 1) : PT_VOTE_INT;
         for (;;) {
             if (active) tr.set_leaf_aside();
 #ifdef PT_POP_FIRST
@@ -474,7 +476,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
 #endif
             const unsigned long long int_mask = __builtin_amdgcn_ballot_w64(tr.wants_interior()) & active_mask;
             const bool w_int = active && tr.wants_interior();
-            const bool go = __builtin_popcountll(int_mask) >= PT_VOTE_INT;
+            const bool go = __builtin_popcountll(int_mask) >= vote_int;
             float4 na, nb, nc, nd;
             if (go && w_int) {
                 const float4 *np = reinterpret_cast<const float4 *>(node_base + size_t(tr.cur << 6));
@@ -507,7 +509,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
         const int n_lvl = count_lanes(w_lvl || w_deep);
         const int n_max = max(max(n_int, n_tri), max(n_ent, n_lvl));
         if (n_max == 0) continue;  // only lanes that are still popping
-        if (n_int >= PT_VOTE_INT) continue;  // pops brought the box-test loop back above its threshold
+        if (n_int >= vote_int) continue;  // pops brought the box-test loop back above its threshold
         // Once the wave has no rays left to hand out, idle lanes stay idle whatever the others do:
         // every operation some lane waits for then runs in every round, so that no ray's last steps
         // are held back by a vote.

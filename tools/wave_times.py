@@ -51,3 +51,11 @@ for rep in range(12):
 print(f"{n} rays, {waves} waves, 10 launches: span median {np.median(spans):.1f} us (min {min(spans):.1f}, max {max(spans):.1f})")
 print(f"wave finish us (medians over launches): first {np.median(p0s):.1f}  p50 {np.median(p50s):.1f}  p99 {np.median(p99s):.1f}  last {np.median(spans):.1f}")
 print(f"wave-time unused after a wave's last ray: {np.median(tails):.4f} of the launch")
+ctr = torch.zeros(n * 4, dtype=torch.int32, device=dev)
+ctx.trace_closest_counted(rays.data_ptr(), n, hits.data_ptr(), ctr.data_ptr())
+ctx.synchronize()
+c = ctr.view(n, 4).cpu().numpy().astype(np.int64)
+steps = c[:, 0] + c[:, 1] + c[:, 3]  # box rounds, instance enters, leaf visits
+print("steps per ray (interior + instances + leaves): mean %.1f  " % steps.mean() + " ".join(f"p{q}={np.percentile(steps, q):.0f}" for q in (50, 90, 99, 99.9, 99.99, 100)))
+order = np.argsort(-steps)[:10]
+print("longest rays: steps", steps[order].tolist(), "at stream positions", (order / n).round(3).tolist())
