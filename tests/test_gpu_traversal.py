@@ -137,6 +137,40 @@ def test_any_hit_on_captured_shadow_rays(pt, ora, gpu_ctx, devbuf, scene_factory
     assert gpu_ctx.stats().shadow_rays >= total
 
 
+@pytest.mark.parametrize("cursors", [None, "1", "3", "64"])
+def test_ragged_batch_sizes_and_work_feed_settings(pt, ora, scene_factory, cursors, monkeypatch):
+    """Every ray of a batch is traced exactly once whatever the batch size (below, at and just above
+    multiples of the 64-ray fetch) and however many work-fetch cursors hand the rays out: untouched
+    entries of the output would keep the 0xFF fill, and double work would show as nothing, so the
+    check is equality with the oracle on every entry."""
+    import torch
+    if cursors is None:
+        monkeypatch.delenv("PTAMD_QUERY_CURSORS", raising=False)
+    else:
+        monkeypatch.setenv("PTAMD_QUERY_CURSORS", cursors)
+    ctx = pt.Context(0)
+    try:
+        hs = scene_factory("teapot", 64, 64, 4)
+        desc = hs.desc()
+        ctx.upload(desc)
+        all_rays = ora.generate_incoherent_rays(desc, 70000, 123)
+        ref_all = ora.trace_closest(desc, all_rays, nthreads=8)
+        dev = torch.device("cuda", 0)
+        for n in (1, 2, 63, 64, 65, 127, 128, 129, 511, 513, 4097, 70000):
+            rays_t = torch.from_numpy(all_rays[:n].view(np.uint8).reshape(-1).copy()).to(dev)
+            hits_t = torch.full((n * 32,), 0xFF, dtype=torch.uint8, device=dev)
+            occ_t = torch.full((n,), 0xFF, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()  # the context launches on a stream of its own
+            ctx.trace_closest(rays_t.data_ptr(), n, hits_t.data_ptr())
+            ctx.trace_any(rays_t.data_ptr(), n, occ_t.data_ptr())
+            ctx.synchronize()
+            hits = hits_t.cpu().numpy().view(pt.abi.HIT)
+            _compare_closest(pt, hits, ref_all[:n], n)
+            assert np.array_equal(occ_t.cpu().numpy(), (ref_all[:n]["inst"] >= 0).astype(np.uint8)), n
+    finally:
+        ctx.close()
+
+
 def test_closest_hit_honours_tmax_and_degenerate_rays(pt, ora, gpu_ctx, scene_factory):
     hs = scene_factory("cornell", 64, 64, 4)
     desc = _upload_scene(gpu_ctx, hs)
