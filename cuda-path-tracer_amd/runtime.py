@@ -103,7 +103,7 @@ def bvh_build(positions: np.ndarray, indices: np.ndarray, geometries: np.ndarray
         lib.pth_bvh_free(h)
 
 
-def render_offscreen(ctx: "Context", scene: "HostScene", iterations: int = 0, batch: int = 16, save_every: int = 0,
+def render_offscreen(ctx: "Context", scene: "HostScene", iterations: int = 0, batch: int = 0, save_every: int = 0,
                      output_prefix: str = None, checkpoint_path: str = None, resume: bool = False) -> dict:
     """Application::Run's offscreen branch (application.cpp:58-76): progressive PNGs, film checkpoint, resume."""
     lib = abi.load_library()

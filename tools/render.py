@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--height", type=int)
     ap.add_argument("--depth", type=int)
     ap.add_argument("--iterations", type=int, default=0, help="0 = the scene's own iteration count")
-    ap.add_argument("--batch", type=int, default=16, help="samples traced per pass")
+    ap.add_argument("--batch", type=int, default=0, help="samples traced per pass (0 = chosen from the iteration count)")
     ap.add_argument("--save-every", type=int, default=0)
     ap.add_argument("--out", default="render", help="output prefix: <out>.<n>samp.png")
     ap.add_argument("--checkpoint")
