@@ -404,8 +404,8 @@ int pt_ctx_create(int device, pt_ctx **out) {
         return Fail(nullptr, PT_ERR_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
     }
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    // one wave per block; LDS stack = kLdsDepth*64*8 B per wave -> 160 KiB / 12 KiB = 13 waves per CU
-    int waves_per_cu = std::min(PT_WAVES_PER_CU, int((160 * 1024) / (kLdsDepth * kWave * sizeof(uint2))));
+    // one wave per block; a wave's LDS (stack + ray stage) bounds the waves that fit a CU's 160 KiB
+    int waves_per_cu = std::min(PT_WAVES_PER_CU, int((160 * 1024) / (kWaveLdsEntries * sizeof(uint2))));
     if (const char *e = getenv("PTAMD_WAVES_PER_CU")) waves_per_cu = std::max(1, std::min(32, atoi(e)));  // tuning aid
     ctx->grid_blocks = uint32_t(ctx->num_cus * waves_per_cu);
     if (const char *e = getenv("PTAMD_QUERY_CURSORS")) ctx->query_cursors = uint32_t(std::max(1, std::min(int(kMaxQueryCursors), atoi(e))));  // tuning aid
