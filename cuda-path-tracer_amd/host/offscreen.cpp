@@ -69,12 +69,14 @@ bool ReadCheckpoint(const std::string &path, int &width, int &height, uint32_t &
 void RenderOffscreen(pt_ctx *ctx, Scene &scene, const pth_offscreen_options &opt, pth_offscreen_result &result) {
     const int width = scene.Width(), height = scene.Height();
     const uint32_t total = opt.iterations ? opt.iterations : uint32_t(scene.MaxIterations());
-    // Samples per pass when the caller leaves it open: a sixteenth of the job, between 8 and 128 (path
-    // state costs 3 x 80 bytes per pixel and sample in flight; beyond 128 the rate no longer grows).
+    // Samples per pass when the caller leaves it open: a sixteenth of the job, between 8 and 128
+    // (beyond 128 the rate no longer grows), and no more than 64 GB of path state: three passes in
+    // flight cost 3 x 80 bytes per pixel and sample.
     uint32_t batch = opt.batch;
     if (batch == 0) {
+        const double bytes_per_sample = 3.0 * 80.0 * double(width) * double(height);
         batch = 8;
-        while (batch < 128 && batch * 32 <= total) batch *= 2;
+        while (batch < 128 && batch * 32 <= total && 2.0 * batch * bytes_per_sample <= 64e9) batch *= 2;
     }
     if (total == 0) throw Exception("RenderOffscreen: nothing to render");
     if (batch > 1024) throw Exception("RenderOffscreen: at most 1024 samples per pass");
