@@ -4,14 +4,14 @@
 so that a later change to the oracle, the host facade or the kernels shows up as a diff against
 committed data.  The reference ships no vectors for this path, so none are derived from it.
 
-    python tools/make_golden.py
+    python tests/golden/make_golden.py
 """
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

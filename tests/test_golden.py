@@ -1,4 +1,4 @@
-"""Committed vectors under tests/golden/ (written by tools/make_golden.py from the CPU oracle on
+"""Committed vectors under tests/golden/ (written by tests/golden/make_golden.py from the CPU oracle on
 scenes this repository builds itself).  The CPU tests check that today's oracle and host facade
 still reproduce them bit for bit; the GPU tests check the HIP kernels against the same files
 through the C ABI.  The reference ships no vectors for this path, so these freeze the restated
