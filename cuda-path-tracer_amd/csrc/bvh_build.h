@@ -965,16 +965,32 @@ __global__ void kb_instance_bounds(const pt_geometry_instance *geoms, uint32_t n
 // bvh.cpp:283-331.  abox = boxes of the live clusters, structure of arrays with stride n.
 // status[0] = 0 on success, 1 when the iteration guard tripped.
 // Every "which cluster gives the smallest merged area with cluster x?" is a scan over the live
-// clusters spread over the workgroup's 1024 lanes; the searches depend on one another (each
+// clusters spread over the workgroup's lanes; the searches depend on one another (each
 // merge or step of the walk decides the next query), so they run one after the other on one CU.
 // (Caching every slot's answer across merges was tried: exact, but the per-merge upkeep cost more
 // than the scans it saved.)
+// Up to kTlasLdsInstances instances the boxes are copied into LDS first and a smaller workgroup
+// runs the chain: a search then costs LDS latency and a 4-wave barrier instead of a round trip to
+// L2 and a 16-wave barrier.
 constexpr uint32_t kTlasThreads = 1024;
+constexpr uint32_t kTlasSmallThreads = 256;
+constexpr uint32_t kTlasLdsInstances = 2048;
 
-__global__ __launch_bounds__(kTlasThreads) void kb_tlas_pairing(pt_tlas_node *tlas, float *abox, uint32_t *active, uint32_t n, uint32_t *status) {
-    __shared__ float s_area[2][kTlasThreads / 64];
-    __shared__ int s_index[2][kTlasThreads / 64];
+template <uint32_t kThreads, bool kBoxesInLds>
+__global__ __launch_bounds__(kThreads) void kb_tlas_pairing(pt_tlas_node *tlas, float *abox_global, uint32_t *active_global, uint32_t n, uint32_t *status) {
+    __shared__ float s_area[2][kThreads / 64];
+    __shared__ int s_index[2][kThreads / 64];
+    __shared__ float s_box[kBoxesInLds ? 6 * kTlasLdsInstances : 1];
+    __shared__ uint32_t s_active[kBoxesInLds ? kTlasLdsInstances : 1];
     const uint32_t tid = threadIdx.x;
+    if (kBoxesInLds) {
+        for (uint32_t i = tid; i < 6 * n; i += kThreads) s_box[i] = abox_global[i];
+        for (uint32_t i = tid; i < n; i += kThreads) s_active[i] = active_global[i];
+        __syncthreads();
+    }
+    // the tables the chain works on: boxes (structure of arrays, stride n) and the node of each live cluster
+    auto abox = [&](uint32_t i) -> float & { return kBoxesInLds ? s_box[i] : abox_global[i]; };
+    auto active = [&](uint32_t i) -> uint32_t & { return kBoxesInLds ? s_active[i] : active_global[i]; };
     int live = int(n);
     uint32_t next_node = 1 + n;
     uint32_t parity = 0;
@@ -986,17 +1002,17 @@ __global__ __launch_bounds__(kTlasThreads) void kb_tlas_pairing(pt_tlas_node *tl
     auto best_partner = [&](int who) -> int {
         float mine_lo[3], mine_hi[3];
         for (int a = 0; a < 3; ++a) {
-            mine_lo[a] = abox[a * n + who];
-            mine_hi[a] = abox[(3 + a) * n + who];
+            mine_lo[a] = abox(a * n + who);
+            mine_hi[a] = abox((3 + a) * n + who);
         }
         float best_area = FLT_MAX;
         int best = -1;
-        for (int j = int(tid); j < live; j += int(kTlasThreads)) {
+        for (int j = int(tid); j < live; j += int(kThreads)) {
             if (j == who) continue;
             RBox m;
             for (int a = 0; a < 3; ++a) {
-                m.lo[a] = fmin_ref(mine_lo[a], abox[a * n + j]);
-                m.hi[a] = fmax_ref(mine_hi[a], abox[(3 + a) * n + j]);
+                m.lo[a] = fmin_ref(mine_lo[a], abox(a * n + j));
+                m.hi[a] = fmax_ref(mine_hi[a], abox((3 + a) * n + j));
             }
             const float area = m.area();
             if (area < best_area) {
@@ -1021,7 +1037,7 @@ __global__ __launch_bounds__(kTlasThreads) void kb_tlas_pairing(pt_tlas_node *tl
         __syncthreads();
         float ba = s_area[parity][0];
         int bi = s_index[parity][0];
-        for (uint32_t w = 1; w < kTlasThreads / 64; ++w) {
+        for (uint32_t w = 1; w < kThreads / 64; ++w) {
             const float oa = s_area[parity][w];
             const int ob = s_index[parity][w];
             if (ob >= 0 && (bi < 0 || oa < ba || (oa == ba && ob < bi))) {
@@ -1050,19 +1066,19 @@ __global__ __launch_bounds__(kTlasThreads) void kb_tlas_pairing(pt_tlas_node *tl
             if (tid == 0) {
                 pt_tlas_node t;
                 for (int k = 0; k < 3; ++k) {
-                    t.min[k] = fmin_ref(abox[k * n + a], abox[k * n + b]);
-                    t.max[k] = fmax_ref(abox[(3 + k) * n + a], abox[(3 + k) * n + b]);
+                    t.min[k] = fmin_ref(abox(k * n + a), abox(k * n + b));
+                    t.max[k] = fmax_ref(abox((3 + k) * n + a), abox((3 + k) * n + b));
                 }
                 t.instance = 0;
-                t.left_right = active[a] | (active[b] << 16);
+                t.left_right = active(a) | (active(b) << 16);
                 tlas[next_node] = t;
-                active[a] = next_node;
-                active[b] = active[live - 1];
+                active(a) = next_node;
+                active(b) = active(live - 1);
                 for (int k = 0; k < 3; ++k) {
-                    abox[k * n + a] = t.min[k];
-                    abox[(3 + k) * n + a] = t.max[k];
+                    abox(k * n + a) = t.min[k];
+                    abox((3 + k) * n + a) = t.max[k];
                 }
-                for (int k = 0; k < 6; ++k) abox[k * n + b] = abox[k * n + (live - 1)];
+                for (int k = 0; k < 6; ++k) abox(k * n + b) = abox(k * n + (live - 1));
             }
             ++next_node;
             --live;
@@ -1074,7 +1090,7 @@ __global__ __launch_bounds__(kTlasThreads) void kb_tlas_pairing(pt_tlas_node *tl
         }
     }
     if (tid == 0) {
-        tlas[0] = tlas[active[a]];
+        tlas[0] = tlas[active(a)];
         status[0] = failed ? 1u : 0u;
     }
 }
@@ -1318,7 +1334,10 @@ inline int BuildOnDevice(hipStream_t stream, const float *positions, uint32_t ve
     PTB_TRY(mem.get(&d_abox, 6 * size_t(geom_count)));
     PTB_TRY(mem.get(&d_active, geom_count));
     hipLaunchKernelGGL(kb_instance_bounds, dim3(Blocks(geom_count)), dim3(256), 0, stream, d_geoms, geom_count, nodes, d_tlas, d_abox, d_active);
-    hipLaunchKernelGGL(kb_tlas_pairing, dim3(1), dim3(kTlasThreads), 0, stream, d_tlas, d_abox, d_active, geom_count, counters + 2);
+    if (geom_count <= kTlasLdsInstances)
+        hipLaunchKernelGGL((kb_tlas_pairing<kTlasSmallThreads, true>), dim3(1), dim3(kTlasSmallThreads), 0, stream, d_tlas, d_abox, d_active, geom_count, counters + 2);
+    else
+        hipLaunchKernelGGL((kb_tlas_pairing<kTlasThreads, false>), dim3(1), dim3(kTlasThreads), 0, stream, d_tlas, d_abox, d_active, geom_count, counters + 2);
     PTB_TRY(hipEventRecord(ev[2], stream));
     PTB_TRY(hipGetLastError());
 
