@@ -973,7 +973,10 @@ __global__ void kb_instance_bounds(const pt_geometry_instance *geoms, uint32_t n
 // runs the chain: a search then costs LDS latency and a 4-wave barrier instead of a round trip to
 // L2 and a 16-wave barrier.
 constexpr uint32_t kTlasThreads = 1024;
-constexpr uint32_t kTlasSmallThreads = 256;
+#ifndef PT_TLAS_SMALL_THREADS
+#define PT_TLAS_SMALL_THREADS 256
+#endif
+constexpr uint32_t kTlasSmallThreads = PT_TLAS_SMALL_THREADS;
 constexpr uint32_t kTlasLdsInstances = 2048;
 
 template <uint32_t kThreads, bool kBoxesInLds>
