@@ -86,6 +86,7 @@ struct pt_ctx {
         hipEvent_t done = nullptr;       // recorded after the lane's last film pass
         bool pending = false;            // `done` has been recorded and not yet joined
     } lane[PT_LANES];
+    bool lane_retired[PT_LANES] = {};  // true once the lane's path state did not fit in device memory: fewer passes in flight
     int cur_lane = 0;            // the lane of the last render
     bool overlap_passes = true;  // off while profiling (events bracket kernels on one stream)
     hipEvent_t fork_event = nullptr;
@@ -917,11 +918,20 @@ static int EnsurePaths(pt_ctx *ctx, pt_ctx::Lane &l, uint32_t samples) {
     PathState &P = l.paths;
     std::memset(&P, 0, sizeof(P));
     int st = PT_OK;
-#define AL(field) if ((st = Alloc(ctx, l.state_allocs, cap, &P.field)) != PT_OK) return st
+    bool ok = true;
+#define AL(field) ok = ok && (st = Alloc(ctx, l.state_allocs, cap, &P.field)) == PT_OK
     AL(ray_o); AL(ray_d); AL(thr); AL(accum); AL(last_pos); AL(rng); AL(hit); AL(hit_inst); AL(sh_o); AL(sh_d); AL(sh_c); AL(sh_q);
     AL(ext_q[0]); AL(ext_q[1]);
     for (int k = 0; k < kNumClasses; ++k) AL(class_q[k]);
 #undef AL
+    if (!ok) {  // give back what was allocated and leave the lane empty, so that a smaller request can succeed
+        FreeAll(l.state_allocs);
+        std::memset(&P, 0, sizeof(P));
+        (void)hipGetLastError();  // the failed allocation's error is reported here, not by a later launch check
+        const std::string why = ctx->error;
+        return Fail(ctx, st, "path state for %u samples per pass at %dx%d (%.1f GB for each pass in flight) does not fit: %s", samples, ctx->width,
+                    ctx->height, double(cap) * 188.0 / 1e9, why.c_str());
+    }
     P.capacity = uint32_t(cap);
     P.slots_per_sample = uint32_t(per_sample);
     l.samples_alloc = samples;
@@ -943,6 +953,7 @@ int pt_integrator_destroy(pt_ctx *ctx) {
     ctx->film = nullptr;
     ctx->integrator_ready = false;
     ctx->width = ctx->height = 0;
+    for (bool &r : ctx->lane_retired) r = false;
     return PT_OK;
 }
 
@@ -1050,7 +1061,34 @@ int pt_render_batch(pt_ctx *ctx, int width, int height, int iteration, int sampl
     // starts after everything submitted to ctx->stream so far, shares nothing mutable with the
     // pass on the other lane except the film, and takes its turn at the film after that pass.
     const bool overlap = ctx->overlap_passes && !ctx->profiling;
-    const int li = overlap ? (ctx->cur_lane + 1) % PT_LANES : 0;
+    // The next usable lane after the one that ran the previous pass.
+    auto next_lane = [&]() {
+        for (int k = 1; k <= PT_LANES; ++k) {
+            const int cand = (ctx->cur_lane + k) % PT_LANES;
+            if (!ctx->lane_retired[cand]) return cand;
+        }
+        return ctx->cur_lane;
+    };
+    int li = overlap ? next_lane() : 0;
+    if (ctx->lane[li].samples_alloc < uint32_t(samples)) {
+        // Path state is allocated before anything of the pass is submitted.  When it does not fit, the
+        // lane is taken out of the rotation and the pass runs on a lane that already holds enough
+        // (fewer passes in flight); the error is reported only when there is no such lane.
+        int st = EnsurePaths(ctx, ctx->lane[li], uint32_t(samples));
+        if (st != PT_OK && overlap) {
+            int fallback = -1;
+            for (int k = 1; k <= PT_LANES && fallback < 0; ++k) {
+                const int cand = (ctx->cur_lane + k) % PT_LANES;
+                if (cand != li && !ctx->lane_retired[cand] && ctx->lane[cand].samples_alloc >= uint32_t(samples)) fallback = cand;
+            }
+            if (fallback >= 0) {
+                ctx->lane_retired[li] = true;
+                li = fallback;
+                st = PT_OK;
+            }
+        }
+        if (st != PT_OK) return st;
+    }
     pt_ctx::Lane &l = ctx->lane[li], &other = ctx->lane[ctx->cur_lane];  // `other` ran the previous pass
     hipStream_t stream = ctx->stream;
     if (overlap) {

@@ -93,7 +93,7 @@ int pth_debug_render(pt_ctx *ctx, int width, int height, pth_scene *scene, const
  * continues after its last iteration - the film ends up bit-identical to an uninterrupted run.  */
 typedef struct pth_offscreen_options {
     uint32_t iterations;   /* 0 = the scene's MaxIterations() */
-    uint32_t batch;        /* samples traced per pass (1..1024), 0 = a sixteenth of the job within 8..128, at most 64 GB of path state */
+    uint32_t batch;        /* samples traced per pass (1..1024), 0 = a sixteenth of the job within 8..128, at most 160 GB of path state */
     uint32_t save_every;   /* 0 = only at the end */
     int32_t resume;
     const char *output_prefix;    /* NULL = no PNG output */
