@@ -919,6 +919,14 @@ static int EnsurePaths(pt_ctx *ctx, pt_ctx::Lane &l, uint32_t samples) {
     std::memset(&P, 0, sizeof(P));
     int st = PT_OK;
     bool ok = true;
+    if (const char *e = getenv("PTAMD_PATH_STATE_LIMIT_MB")) {  // testing aid: a smaller device, as far as path state goes
+        size_t held = cap;
+        for (const pt_ctx::Lane &o : ctx->lane) held += size_t(o.samples_alloc) * per_sample;
+        if (double(held) * 188.0 > atof(e) * 1e6) {
+            ok = false;
+            st = Fail(ctx, PT_ERR_DEVICE, "PTAMD_PATH_STATE_LIMIT_MB=%s", e);
+        }
+    }
 #define AL(field) ok = ok && (st = Alloc(ctx, l.state_allocs, cap, &P.field)) == PT_OK
     AL(ray_o); AL(ray_d); AL(thr); AL(accum); AL(last_pos); AL(rng); AL(hit); AL(hit_inst); AL(sh_o); AL(sh_d); AL(sh_c); AL(sh_q);
     AL(ext_q[0]); AL(ext_q[1]);

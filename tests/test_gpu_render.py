@@ -229,6 +229,39 @@ def test_batched_samples_equal_separate_renders(pt, gpu_ctx, scene_factory):
         gpu_ctx.render_batch(w, h, 0, 0)
 
 
+def test_passes_in_flight_shrink_when_path_state_does_not_fit(pt, gpu_ctx, scene_factory, monkeypatch):
+    """With room for the path state of two passes in flight but not three, the third lane is
+    retired and rendering goes on: same film, bit for bit.  A pass that does not fit even once is an
+    error that names what it needed, and leaves the context usable."""
+    w, h = 96, 72
+    hs = scene_factory("teapot", w, h, 6)
+    gpu_ctx.upload(hs.desc())
+    gpu_ctx.integrator_init(w, h)
+    for k in range(6):
+        gpu_ctx.render_batch(w, h, 4 * k, 4)
+    gpu_ctx.synchronize()
+    expected = gpu_ctx.film_download(w, h)
+    # 6912 path slots per sample x 188 B = 1.3 MB: 12 samples in flight are 15.6 MB, 8 are 10.4 MB
+    monkeypatch.setenv("PTAMD_PATH_STATE_LIMIT_MB", "13")
+    small = pt.Context(0)
+    try:
+        small.upload(hs.desc())
+        small.integrator_init(w, h)
+        for k in range(6):  # the third pass asks for a third lane's state: refused by the limit, so it must fall back
+            small.render_batch(w, h, 4 * k, 4)
+        small.synchronize()
+        assert np.array_equal(small.film_download(w, h).view(np.uint32), expected.view(np.uint32))
+        with pytest.raises(pt.PtError, match="does not fit"):
+            small.render_batch(w, h, 24, 16)
+        small.render_batch(w, h, 0, 4)  # iteration 0 clears the film
+        for k in range(1, 6):
+            small.render_batch(w, h, 4 * k, 4)
+        small.synchronize()
+        assert np.array_equal(small.film_download(w, h).view(np.uint32), expected.view(np.uint32))
+    finally:
+        small.close()
+
+
 def test_large_frame_is_deterministic_and_counts_match_oracle(pt, ora, gpu_ctx, scene_factory):
     """Queue staging, grouped work fetches and lane refill only show their corner cases with many
     waves in flight: at 960x540 the per-bounce ray counts must repeat exactly from call to call and
