@@ -44,8 +44,7 @@ struct PathState {
     float4 *accum;     // accumulated radiance.xyz
     float4 *last_pos;  // last surface position.xyz
     uint2 *rng;        // PCG state
-    float4 *hit;       // t, u, v, bits(triangle record)
-    int *hit_inst;
+    float4 *hit;       // bits(instance), u, v, bits(triangle record) of the last closest hit
     float4 *sh_o;      // shadow ray origin.xyz, tmax        (indexed by path slot, like everything above)
     float4 *sh_d;      // shadow ray direction.xyz
     float4 *sh_c;      // contribution added when unoccluded
@@ -310,8 +309,7 @@ struct ExtendIO {
     PTD bool has_pending() const { return pending; }
     template <class TR>
     PTD void done(uint32_t, uint32_t slot, const TR &tr, bool hit) {
-        P.hit_inst[slot] = hit ? tr.hit.inst : -1;
-        if (!hit) {
+        if (!hit) {  // a miss ends the path here: it enters no class queue, so no hit record is kept
             if (tr.t_max > FLT_MAX) {  // the black environment adds throughput * 0: NaN iff the throughput is not finite
                 const float4 t = P.thr[slot];
                 float4 a = P.accum[slot];
@@ -322,7 +320,7 @@ struct ExtendIO {
             }
             return;
         }
-        P.hit[slot] = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, as_f(tr.hit.rec));
+        P.hit[slot] = make_float4(as_f(uint32_t(tr.hit.inst)), tr.hit.u, tr.hit.v, as_f(tr.hit.rec));
         const uint32_t type = as_u(reinterpret_cast<const float4 *>(S.insts + tr.hit.inst)[3].z);
         pend_cls = type == PT_MAT_LAMBERTIAN ? 1 : type == PT_MAT_MIRROR ? 2 : type == PT_MAT_METALLIC_ROUGHNESS ? 3
                    : type == PT_MAT_DIELECTRIC ? 4 : 0;
@@ -471,12 +469,12 @@ __global__ __launch_bounds__(64) void k_shade(DScene S, PathState P, BounceCount
             V3 throughput = mk3(thr4.x, thr4.y, thr4.z);
             const float4 acc4 = P.accum[slot];
             V3 accum = mk3(acc4.x, acc4.y, acc4.z);
-            const int inst = P.hit_inst[slot];
+            const float4 h4 = P.hit[slot];
+            const int inst = int(as_u(h4.x));
             if (cls == 0) {
                 if (inst < 0) {
                     accum = accum + throughput * splat(0.0f);  // black environment, path_trace.cu:351-356
                 } else {
-                    const float4 h4 = P.hit[slot];
                     const Isect is = resolve_hit(S, ro, rd, h4.y, h4.z, as_u(h4.w), inst);
                     const DMaterial m = S.materials[is.material_id];
                     const float4 fm = reinterpret_cast<const float4 *>(S.fwd + inst)[6];
@@ -500,7 +498,6 @@ __global__ __launch_bounds__(64) void k_shade(DScene S, PathState P, BounceCount
                 P.accum[slot] = make_float4(accum.x, accum.y, accum.z, 0.0f);
             } else {
                 // ---- level A: the rest of the path state (requested together with the loads above)
-                const float4 h4 = P.hit[slot];
                 const uint2 r2 = P.rng[slot];
                 uint64_t rng = uint64_t(r2.x) | (uint64_t(r2.y) << 32);
                 const float hu = h4.y, hv = h4.z;

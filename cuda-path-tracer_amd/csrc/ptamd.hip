@@ -922,13 +922,13 @@ static int EnsurePaths(pt_ctx *ctx, pt_ctx::Lane &l, uint32_t samples) {
     if (const char *e = getenv("PTAMD_PATH_STATE_LIMIT_MB")) {  // testing aid: a smaller device, as far as path state goes
         size_t held = cap;
         for (const pt_ctx::Lane &o : ctx->lane) held += size_t(o.samples_alloc) * per_sample;
-        if (double(held) * 188.0 > atof(e) * 1e6) {
+        if (double(held) * 184.0 > atof(e) * 1e6) {
             ok = false;
             st = Fail(ctx, PT_ERR_DEVICE, "PTAMD_PATH_STATE_LIMIT_MB=%s", e);
         }
     }
 #define AL(field) ok = ok && (st = Alloc(ctx, l.state_allocs, cap, &P.field)) == PT_OK
-    AL(ray_o); AL(ray_d); AL(thr); AL(accum); AL(last_pos); AL(rng); AL(hit); AL(hit_inst); AL(sh_o); AL(sh_d); AL(sh_c); AL(sh_q);
+    AL(ray_o); AL(ray_d); AL(thr); AL(accum); AL(last_pos); AL(rng); AL(hit); AL(sh_o); AL(sh_d); AL(sh_c); AL(sh_q);
     AL(ext_q[0]); AL(ext_q[1]);
     for (int k = 0; k < kNumClasses; ++k) AL(class_q[k]);
 #undef AL
@@ -938,7 +938,7 @@ static int EnsurePaths(pt_ctx *ctx, pt_ctx::Lane &l, uint32_t samples) {
         (void)hipGetLastError();  // the failed allocation's error is reported here, not by a later launch check
         const std::string why = ctx->error;
         return Fail(ctx, st, "path state for %u samples per pass at %dx%d (%.1f GB for each pass in flight) does not fit: %s", samples, ctx->width,
-                    ctx->height, double(cap) * 188.0 / 1e9, why.c_str());
+                    ctx->height, double(cap) * 184.0 / 1e9, why.c_str());
     }
     P.capacity = uint32_t(cap);
     P.slots_per_sample = uint32_t(per_sample);

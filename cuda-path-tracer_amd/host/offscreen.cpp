@@ -70,11 +70,11 @@ void RenderOffscreen(pt_ctx *ctx, Scene &scene, const pth_offscreen_options &opt
     const int width = scene.Width(), height = scene.Height();
     const uint32_t total = opt.iterations ? opt.iterations : uint32_t(scene.MaxIterations());
     // Samples per pass when the caller leaves it open: a sixteenth of the job, between 8 and 128
-    // (beyond 128 the rate no longer grows), and no more than 160 GB of path state: 188 bytes per
+    // (beyond 128 the rate no longer grows), and no more than 160 GB of path state: 184 bytes per
     // pixel and sample for each of the three passes in flight.
     uint32_t batch = opt.batch;
     if (batch == 0) {
-        const double bytes_per_sample = 3.0 * 188.0 * double(width) * double(height);
+        const double bytes_per_sample = 3.0 * 184.0 * double(width) * double(height);
         batch = 8;
         while (batch < 128 && batch * 32 <= total && 2.0 * batch * bytes_per_sample <= 160e9) batch *= 2;
     }

@@ -241,7 +241,7 @@ def test_passes_in_flight_shrink_when_path_state_does_not_fit(pt, gpu_ctx, scene
         gpu_ctx.render_batch(w, h, 4 * k, 4)
     gpu_ctx.synchronize()
     expected = gpu_ctx.film_download(w, h)
-    # 6912 path slots per sample x 188 B = 1.3 MB: 12 samples in flight are 15.6 MB, 8 are 10.4 MB
+    # 6912 path slots per sample x 184 B = 1.3 MB: 12 samples in flight are 15.6 MB, 8 are 10.4 MB
     monkeypatch.setenv("PTAMD_PATH_STATE_LIMIT_MB", "13")
     small = pt.Context(0)
     try:

@@ -14,7 +14,7 @@ free0, total = torch.cuda.mem_get_info()
 print("free GB before", free0 / 1e9)
 try:
     for k in range(4):
-        ctx.render_batch(W, H, k * 80, 80)   # 188 B x 8.3 M x 80 = 125 GB per pass in flight: two fit, the third does not
+        ctx.render_batch(W, H, k * 80, 80)   # 184 B x 8.3 M x 80 = 122 GB per pass in flight: two fit, the third does not
         f, _ = torch.cuda.mem_get_info()
         print("pass", k, "submitted, free GB", f / 1e9)
     ctx.synchronize()
