@@ -467,11 +467,11 @@ __global__ __launch_bounds__(64) void k_shade(DScene S, PathState P, BounceCount
             int remaining_bounces = int(as_u(rd4.w) & ~kThroughputNotFinite);
             const float4 thr4 = P.thr[slot];
             V3 throughput = mk3(thr4.x, thr4.y, thr4.z);
-            const float4 acc4 = P.accum[slot];
-            V3 accum = mk3(acc4.x, acc4.y, acc4.z);
             const float4 h4 = P.hit[slot];
             const int inst = int(as_u(h4.x));
             if (cls == 0) {
+                const float4 acc4 = P.accum[slot];  // only emissive hits add radiance here
+                V3 accum = mk3(acc4.x, acc4.y, acc4.z);
                 if (inst < 0) {
                     accum = accum + throughput * splat(0.0f);  // black environment, path_trace.cu:351-356
                 } else {
