@@ -104,6 +104,7 @@ struct pt_ctx {
     std::vector<EventPair> free_events;
     pt_stats stats;
     int trace_mode = 0;
+    bool host_may_block = false;  // set by the synchronous entry points around RunBounces
 };
 
 namespace {
@@ -287,7 +288,8 @@ int Validate(pt_ctx *ctx, const pt_scene_desc *d) {
         if (d->materials[i].type > PT_MAT_EMISSIVE) return Fail(ctx, PT_ERR_INVALID, "material %u: unknown type", i);
     for (uint32_t i = 0; i < d->light_count; ++i) {
         const int gi = d->lights[i].geometry_instance_index;
-        if (gi < 0 || uint32_t(gi) >= d->geometry_count) return Fail(ctx, PT_ERR_INVALID, "light %u: bad instance", i);
+        // -1 is a light without geometry: SampleSceneLight returns a black sample after one draw (kernel/light.h:18-19)
+        if (gi < -1 || (gi >= 0 && uint32_t(gi) >= d->geometry_count)) return Fail(ctx, PT_ERR_INVALID, "light %u: bad instance", i);
     }
     if (d->light_count > 0) {
         if (d->light_sampler->size != d->light_count) return Fail(ctx, PT_ERR_INVALID, "light sampler size differs from light count");
@@ -1041,8 +1043,10 @@ static int RunBounces(pt_ctx *ctx, pt_ctx::Lane &l, hipStream_t stream, int widt
             ScopedEvent ev(timed ? ctx : nullptr, EV_ANY);
             hipLaunchKernelGGL(k_shadow, grid_shadow, block, 0, stream, S, P, l.counters, b, l.spill, ctx->spill_stride, ctx->dev_stats);
         }
-        // long depth limits: stop launching once the extension queue has drained
-        if ((b & 7) == 7 && b + 1 < bounces) {
+        // Long depth limits: stop launching once the extension queue has drained.  Only a call that blocks
+        // the host anyway (pt_render, the ray captures) reads the counter back for that; an asynchronous
+        // pass is submitted whole, and the persistent kernels of a drained bounce return at once.
+        if (ctx->host_may_block && (b & 7) == 7 && b + 1 < bounces) {
             HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned_word, &l.counters[b + 1].ext_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(ctx, hipStreamSynchronize(stream));
             if (*ctx->pinned_word == 0) {
@@ -1144,7 +1148,10 @@ int pt_render_async(pt_ctx *ctx, int width, int height, int iteration, uint8_t *
 }
 
 int pt_render(pt_ctx *ctx, int width, int height, int iteration, uint8_t *rgba_device) {
+    if (!ctx) return PT_ERR_INVALID;
+    ctx->host_may_block = true;
     int st = pt_render_async(ctx, width, height, iteration, rgba_device);
+    ctx->host_may_block = false;
     if (st != PT_OK) return st;
     DeviceGuard guard(ctx->device);
     HIP_TRY(ctx, SyncAll(ctx));  // path_trace.cu:481
@@ -1155,6 +1162,7 @@ int pt_film_download(pt_ctx *ctx, float *rgb_host) {
     if (!ctx || !rgb_host) return PT_ERR_INVALID;
     if (!ctx->integrator_ready) return Fail(ctx, PT_ERR_STATE, "no film: integrator not initialised");
     DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, Join(ctx));  // the copy must come after the film passes still running on the lanes' streams
     HIP_TRY(ctx, hipMemcpyAsync(rgb_host, ctx->film, size_t(ctx->width) * ctx->height * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, SyncAll(ctx));
     return PT_OK;
@@ -1164,6 +1172,7 @@ int pt_film_copy_to_device(pt_ctx *ctx, float *rgb_device) {
     if (!ctx || !rgb_device) return PT_ERR_INVALID;
     if (!ctx->integrator_ready) return Fail(ctx, PT_ERR_STATE, "no film: integrator not initialised");
     DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, Join(ctx));
     HIP_TRY(ctx, hipMemcpyAsync(rgb_device, ctx->film, size_t(ctx->width) * ctx->height * 3 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, SyncAll(ctx));
     return PT_OK;
@@ -1173,6 +1182,7 @@ int pt_film_copy_from_device(pt_ctx *ctx, const float *rgb_device) {
     if (!ctx || !rgb_device) return PT_ERR_INVALID;
     if (!ctx->integrator_ready) return Fail(ctx, PT_ERR_STATE, "no film: integrator not initialised");
     DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, Join(ctx));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->film, rgb_device, size_t(ctx->width) * ctx->height * 3 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, SyncAll(ctx));
     return PT_OK;
@@ -1213,6 +1223,7 @@ int pt_tonemap(pt_ctx *ctx, const float *film_device, int width, int height, int
         film_device = ctx->film;
     }
     DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, Join(ctx));  // the context's film may still be receiving samples on a lane's stream
     const uint32_t n = uint32_t(width) * uint32_t(height);
     hipLaunchKernelGGL(k_tonemap, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, film_device, rgba_device, width, height, iterations);
     HIP_TRY(ctx, hipGetLastError());
@@ -1381,7 +1392,9 @@ int pt_capture_shadow_rays(pt_ctx *ctx, int width, int height, int iteration, in
     HIP_TRY(ctx, Join(ctx));
     pt_ctx::Lane &l = ctx->lane[0];
     ctx->cur_lane = 0;
+    ctx->host_may_block = true;
     int st = RunBounces(ctx, l, ctx->stream, width, height, iteration, 1, bounce + 1, true);
+    ctx->host_may_block = false;
     ctx->last_render_samples = 1;
     if (st != PT_OK) return st;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned_word, &l.counters[bounce].shadow_count, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -1472,7 +1485,9 @@ int pt_capture_bounce_rays(pt_ctx *ctx, int width, int height, int iteration, in
     HIP_TRY(ctx, Join(ctx));
     pt_ctx::Lane &l = ctx->lane[0];
     ctx->cur_lane = 0;
+    ctx->host_may_block = true;
     int st = RunBounces(ctx, l, ctx->stream, width, height, iteration, 1, bounce + 1, false);
+    ctx->host_may_block = false;
     ctx->last_render_samples = 1;
     if (st != PT_OK) return st;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned_word, &l.counters[bounce].ext_count, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -242,7 +242,7 @@ struct Traversal {
             }
         }
         if (COUNT) ctr.tris++;
-        const float4 *tp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(S.tris) + size_t(tri_next * uint32_t(sizeof(DTri))));
+        const float4 *tp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(S.tris) + size_t(tri_next) * sizeof(DTri));
         const float4 ta = tp[0], tb = tp[1], tc = tp[2];
         float t, u, v;
         const bool ok = tri_test(co, cd, ta, tb, tc, t_max, t, u, v);
@@ -479,7 +479,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
             const bool go = __builtin_popcountll(int_mask) >= vote_int;
             float4 na, nb, nc, nd;
             if (go && w_int) {
-                const float4 *np = reinterpret_cast<const float4 *>(node_base + size_t(tr.cur << 6));
+                const float4 *np = reinterpret_cast<const float4 *>(node_base + (size_t(tr.cur) << 6));
                 na = np[0];
                 nb = np[1];
                 nc = np[2];
@@ -517,7 +517,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
         if (n_int == n_max || (drain && n_int > 0)) {  // fewer than PT_VOTE_INT lanes, but still the largest group
             if (w_int) {
                 PT_PHASE(ev, 0);
-                const float4 *np = reinterpret_cast<const float4 *>(node_base + size_t(tr.cur << 6));
+                const float4 *np = reinterpret_cast<const float4 *>(node_base + (size_t(tr.cur) << 6));
                 tr.op_interior(stk, ev, np[0], np[1], np[2], np[3]);
             }
         }

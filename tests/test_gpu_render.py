@@ -229,6 +229,75 @@ def test_batched_samples_equal_separate_renders(pt, gpu_ctx, scene_factory):
         gpu_ctx.render_batch(w, h, 0, 0)
 
 
+def test_film_access_waits_for_passes_in_flight(pt, gpu_ctx, scene_factory, devbuf):
+    """Film reads, copies and tone mapping are ordered after the passes still running on the
+    library's own streams: no pt_synchronize between pt_render_batch and the film access."""
+    import torch
+
+    w, h = 160, 120
+    hs = scene_factory("helmet", w, h, 8)
+    gpu_ctx.upload(hs.desc())
+    gpu_ctx.integrator_init(w, h)
+    for k in range(3):
+        gpu_ctx.render_batch(w, h, 8 * k, 8)
+    gpu_ctx.synchronize()
+    expected = gpu_ctx.film_download(w, h)
+    expected_rgba = gpu_ctx.display_download(w, h, 24)
+    for access in ("download", "copy", "tonemap"):
+        for k in range(3):
+            gpu_ctx.render_batch(w, h, 8 * k, 8)
+        if access == "download":
+            got = gpu_ctx.film_download(w, h)
+        elif access == "copy":
+            dev = devbuf(w * h * 12)
+            gpu_ctx.film_copy_to_device(dev.ptr)
+            got = dev.download(np.float32, w * h * 3).reshape(h, w, 3)
+        else:
+            dev = devbuf(w * h * 4)
+            gpu_ctx.tonemap(0, w, h, 24, dev.ptr)
+            assert np.array_equal(dev.download(np.uint8, w * h * 4).reshape(h, w, 4), expected_rgba)
+            continue
+        assert np.array_equal(got.view(np.uint32), expected.view(np.uint32)), access
+    del torch
+
+
+def test_light_without_geometry_samples_black(pt, ora, gpu_ctx, tiny_scene):
+    """An AreaLight whose geometry_instance_index is -1 is valid input: picking it costs one random
+    draw and yields a black sample (kernel/light.h:18-19).  Same film as the oracle's."""
+    import ctypes as C
+
+    w, h = 64, 48
+    arr = tiny_scene.arrays()
+    d = pt.abi.SceneDesc.from_buffer_copy(tiny_scene.desc())
+    lights = np.zeros(len(arr["lights"]) + 1, pt.abi.AREA_LIGHT)
+    lights[:-1] = arr["lights"]
+    lights[-1]["power"] = arr["lights"]["power"].sum() * 0.5
+    lights[-1]["geometry_instance_index"] = -1
+    prob, alias = pt.alias_build(lights["power"].astype(np.float32))
+    table = pt.abi.AliasTable()
+    table.alias_table = alias.ctypes.data_as(C.POINTER(C.c_uint32))
+    table.probability_table = prob.ctypes.data_as(C.POINTER(C.c_float))
+    table.size = len(lights)
+    d.lights, d.light_count = lights.ctypes.data, len(lights)
+    d.light_sampler = C.pointer(table)
+    d.total_light_power = float(np.float32(lights["power"].sum()))
+    gpu_ctx.upload(d)
+    gpu_ctx.integrator_init(w, h)
+    ref = None
+    for it in range(2):
+        gpu_ctx.render(w, h, it)
+        ref, _ = ora.render(d, w, h, it, ref, nthreads=8)
+    film = gpu_ctx.film_download(w, h)
+    close = (np.abs(film - ref) <= 1e-4 + 1e-3 * np.abs(ref)).all(axis=2)
+    assert close.mean() >= 0.97 and ref.mean() > 1e-3
+    # the extra light takes a third of the picks: the film is darker than the plain scene's
+    gpu_ctx.upload(tiny_scene.desc())
+    gpu_ctx.integrator_init(w, h)
+    for it in range(2):
+        gpu_ctx.render(w, h, it)
+    assert film.mean() < gpu_ctx.film_download(w, h).mean()
+
+
 def test_passes_in_flight_shrink_when_path_state_does_not_fit(pt, gpu_ctx, scene_factory, monkeypatch):
     """With room for the path state of two passes in flight but not three, the third lane is
     retired and rendering goes on: same film, bit for bit.  A pass that does not fit even once is an
