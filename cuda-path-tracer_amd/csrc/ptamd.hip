@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -39,9 +40,40 @@ constexpr uint32_t kMaxQueryCursors = 64;
 
 using namespace ptd;
 
+// Scratch of pt_trace_closest_static, the entry point that allocates nothing: the work-feed cursors,
+// the event counters and the traversal-stack spill area of a grid of kStaticWaves persistent waves.
+// Every GPU the library runs on holds its own copy of this array until the process ends; the name
+// below is only the host-side handle of the symbol, the device address is looked up once per device
+// (StaticScratch) and that pointer is what kernels and memsets receive.
+constexpr uint32_t kStaticWaves = 1024;
+constexpr size_t kStaticCursorBytes = size_t(kMaxQueryCursors) * kCursorStride * sizeof(uint32_t);
+constexpr size_t kStaticStatsOffset = kStaticCursorBytes;
+constexpr size_t kStaticSpillOffset = kStaticCursorBytes + 256;
+constexpr size_t kStaticSpillBytes = size_t(kStaticWaves) * kWave * kSpillDepth * sizeof(uint2);
+constexpr size_t kStaticScratchBytes = kStaticSpillOffset + kStaticSpillBytes;  // 60 MiB + 16.25 KiB
+static_assert(sizeof(DevStats) <= 256, "the counters fit their slot");
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
 namespace {
 
 thread_local std::string g_create_error;
+
+constexpr int kMaxDevices = 64;
+std::mutex g_static_mutex;
+unsigned char *g_static_ptr[kMaxDevices] = {};  // device address of `scratch` on each GPU, filled by pt_ctx_create
+
+// The address of this device's copy of `scratch`; `device` must be the current device.
+hipError_t StaticScratch(int device, unsigned char **out) {
+    std::lock_guard<std::mutex> lock(g_static_mutex);
+    if (!g_static_ptr[device]) {
+        void *p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_static_ptr[device] = static_cast<unsigned char *>(p);
+    }
+    *out = g_static_ptr[device];
+    return hipSuccess;
+}
 
 struct EventPair {
     hipEvent_t start, stop;
@@ -70,6 +102,7 @@ struct pt_ctx {
     uint32_t *cursor = nullptr;  // work-fetch cursors of the batch queries, kCursorStride words apart
     uint32_t query_cursors = PT_QUERY_CURSORS;
     DevStats *dev_stats = nullptr;
+    unsigned char *static_scratch = nullptr;  // this device's copy of the file-scope `scratch` array
 
     // integrator.  Everything a render pass mutates besides the film exists twice ("lanes"):
     // consecutive pt_render_batch calls alternate between the lanes and run on the lanes' own
@@ -390,6 +423,7 @@ int pt_ctx_create(int device, pt_ctx **out) {
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count == 0) return Fail(nullptr, PT_ERR_DEVICE, "no HIP device available: %s", hipGetErrorString(e));
     if (device < 0 || device >= count) return Fail(nullptr, PT_ERR_INVALID, "device %d out of range (%d devices)", device, count);
+    if (device >= kMaxDevices) return Fail(nullptr, PT_ERR_LIMIT, "device %d: at most %d devices are supported", device, kMaxDevices);
     pt_ctx *ctx = new pt_ctx();
     ctx->device = device;
     std::memset(&ctx->scene, 0, sizeof(ctx->scene));
@@ -407,6 +441,11 @@ int pt_ctx_create(int device, pt_ctx **out) {
         return Fail(nullptr, PT_ERR_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
     }
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    e = StaticScratch(device, &ctx->static_scratch);  // `device` is current here (DeviceGuard above)
+    if (e != hipSuccess) {
+        delete ctx;
+        return Fail(nullptr, PT_ERR_DEVICE, "hipGetSymbolAddress(scratch): %s", hipGetErrorString(e));
+    }
     // one wave per block; a wave's LDS (stack + ray stage) bounds the waves that fit a CU's 160 KiB
     int waves_per_cu = std::min(PT_WAVES_PER_CU, int((160 * 1024) / (kWaveLdsEntries * sizeof(uint2))));
     if (const char *e = getenv("PTAMD_WAVES_PER_CU")) waves_per_cu = std::max(1, std::min(32, atoi(e)));  // tuning aid
@@ -1254,6 +1293,28 @@ int pt_trace_closest(pt_ctx *ctx, const pt_ray *rays, size_t n, pt_hit *hits) {
         hipLaunchKernelGGL(k_trace_closest<false>, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors,
                            ctx->lane[0].spill, ctx->spill_stride, ctx->dev_stats, static_cast<TraceCounters *>(nullptr));
     }
+    HIP_TRY(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+// pt_trace_closest with every piece of scratch in this device's copy of the static array: no
+// allocation, no event creation, nothing shared with the render passes (hence no join with them).
+int pt_trace_closest_static(pt_ctx *ctx, const pt_ray *rays, size_t n, pt_hit *hits) {
+    int st = CheckQuery(ctx, rays, hits, n);
+    if (st != PT_OK) return st;
+    if (n > PT_STATIC_MAX_RAYS) return Fail(ctx, PT_ERR_LIMIT, "pt_trace_closest_static: %zu rays exceed the limit of %zu per call", n, size_t(PT_STATIC_MAX_RAYS));
+    if (n == 0) return PT_OK;
+    if ((reinterpret_cast<uintptr_t>(hits) & 15u) != 0) return Fail(ctx, PT_ERR_INVALID, "hit buffer must be 16-byte aligned");
+    DeviceGuard guard(ctx->device);
+    unsigned char *base = ctx->static_scratch;
+    uint32_t *cursors = reinterpret_cast<uint32_t *>(base);
+    DevStats *stats = reinterpret_cast<DevStats *>(base + kStaticStatsOffset);
+    uint2 *spill = reinterpret_cast<uint2 *>(base + kStaticSpillOffset);
+    // cursors and counters start at zero; the spill area is written before it is read
+    HIP_TRY(ctx, hipMemsetAsync(base, 0, kStaticSpillOffset, ctx->stream));
+    const uint32_t blocks = uint32_t(std::min<size_t>(std::min<uint32_t>(ctx->grid_blocks, kStaticWaves), (n + kWave - 1) / kWave));
+    hipLaunchKernelGGL(k_trace_closest<false>, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, cursors, ctx->query_cursors, spill,
+                       kStaticWaves * uint32_t(kWave), stats, static_cast<TraceCounters *>(nullptr));
     HIP_TRY(ctx, hipGetLastError());
     return PT_OK;
 }

@@ -435,6 +435,10 @@ class Context:
     def trace_closest(self, rays_ptr: int, n: int, hits_ptr: int):
         self._check(self._lib.pt_trace_closest(self._h, C.c_void_p(rays_ptr), n, C.c_void_p(hits_ptr)))
 
+    def trace_closest_static(self, rays_ptr: int, n: int, hits_ptr: int):
+        """pt_trace_closest with its scratch in the library's static device array: allocates nothing."""
+        self._check(self._lib.pt_trace_closest_static(self._h, C.c_void_p(rays_ptr), n, C.c_void_p(hits_ptr)))
+
     def trace_any(self, rays_ptr: int, n: int, occluded_ptr: int):
         self._check(self._lib.pt_trace_any(self._h, C.c_void_p(rays_ptr), n, C.c_void_p(occluded_ptr)))
 

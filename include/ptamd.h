@@ -403,6 +403,17 @@ int pt_resolve_hits(pt_ctx *ctx, const pt_ray *rays_device, const pt_hit *hits_d
  * callback hook (kernel/intersection.h:24-31,61,181) as a query. counters4 = n * 4 uint32. */
 int pt_trace_closest_counted(pt_ctx *ctx, const pt_ray *rays_device, size_t n, pt_hit *hits_device,
                              uint32_t *counters4_device);
+/* pt_trace_closest for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): no counterpart in the reference.  The call allocates
+ * nothing and creates no events: its scratch (work-feed cursors, event counters, traversal-stack
+ * spill area for 1024 persistent waves) is a file-scope device array of 60 MiB + 16.25 KiB that every
+ * GPU the library runs on holds until the process ends.  Results are those of pt_trace_closest, bit
+ * for bit.  n > PT_STATIC_MAX_RAYS returns PT_ERR_LIMIT.  All calls on one GPU share that GPU's
+ * array: calls that overlap on one GPU (two contexts, two streams) race; calls on one stream do not.
+ * Stack spills / drops of these calls are not added to pt_stats.  Asynchronous on the context's
+ * stream like pt_trace_closest.                                                               */
+#define PT_STATIC_MAX_RAYS ((size_t)1 << 26)
+int pt_trace_closest_static(pt_ctx *ctx, const pt_ray *rays_device, size_t n, pt_hit *hits_device);
 /* Host-pointer conveniences (stage through device memory, synchronous). */
 int pt_trace_closest_host(pt_ctx *ctx, const pt_ray *rays, size_t n, pt_hit *hits);
 int pt_trace_any_host(pt_ctx *ctx, const pt_ray *rays, size_t n, uint8_t *occluded);
