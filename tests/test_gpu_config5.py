@@ -1,0 +1,129 @@
+"""Configuration 5 at its own scale: the reference's scripts/armadillo.py scene (2 x 10 000 instances,
+restated with a seed and stand-in meshes by tools/cook_scenes.py::party_armadillo) on the GPU
+against the CPU oracle, through the C ABI.  20 001 instances is near the 32 767 the reference's
+16-bit TLAS child indices allow.
+
+Bars: traversal bit-equal to the oracle (ids, distances, barycentrics, visit counts); one-sample
+film parity per pixel to |d| <= 1e-4 + 1e-3 |ref| on >= 97 % of the pixels (the others took a
+different, equally valid path after a one-ulp transcendental difference); the 4K frame, which the
+oracle cannot render in test time, is checked through properties: bitwise repeatability, exact
+per-bounce ray counts from call to call, one path per pixel, no dropped stack pushes, no NaNs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SCENE = "party_armadillo"
+
+
+@pytest.fixture(scope="module")
+def party(scene_factory):
+    return scene_factory(SCENE, 128, 72, 8)
+
+
+def test_scene_is_at_the_reference_scale(pt, party):
+    arr = party.arrays()
+    assert len(arr["geometries"]) == 20001 and len(arr["tlas_nodes"]) == 2 * 20001
+    assert len(arr["blases"]) == 3 and len(arr["lights"]) == 1
+    # material ids in key order after the default: diffuse_red 1, light 2, mirror 3 (scene.cpp:337-356)
+    mats = arr["materials"]["type"]
+    assert list(mats[:4]) == [pt.abi.PT_MAT_LAMBERTIAN, pt.abi.PT_MAT_LAMBERTIAN, pt.abi.PT_MAT_EMISSIVE, pt.abi.PT_MAT_MIRROR]
+    used = np.bincount(arr["geometries"]["material_id"], minlength=4)
+    assert used[1] == 10000 and used[3] == 10000 and used[2] == 1
+
+
+def test_closest_and_any_hit_match_oracle_on_200k_rays(pt, ora, gpu_ctx, devbuf, party):
+    desc = party.desc()
+    gpu_ctx.upload(desc)
+    n = 200000
+    rays_d, hits_d, ctr_d, occ_d = devbuf(n * 32), devbuf(n * 32), devbuf(n * 16), devbuf(n)
+    gpu_ctx.generate_incoherent_rays(rays_d.ptr, n, 77)
+    gpu_ctx.reset_stats()
+    gpu_ctx.trace_closest_counted(rays_d.ptr, n, hits_d.ptr, ctr_d.ptr)
+    gpu_ctx.trace_any(rays_d.ptr, n, occ_d.ptr)
+    gpu_ctx.synchronize()
+    rays = rays_d.download(pt.abi.RAY, n)
+    hits = hits_d.download(pt.abi.HIT, n)
+    ctr = ctr_d.download(np.uint32, n * 4).reshape(n, 4).astype(np.uint64).sum(axis=0)
+    occ = occ_d.download(np.uint8, n)
+    ref, ref_ctr = ora.trace_closest(desc, rays, nthreads=8, counters=True)
+    assert (ref["inst"] >= 0).mean() > 0.5 and len(np.unique(ref["inst"])) > 5000
+    for f in ("prim", "inst", "material_id"):
+        assert np.array_equal(hits[f], ref[f]), f
+    for f in ("t", "u", "v"):
+        assert np.array_equal(hits[f].view(np.uint32), ref[f].view(np.uint32)), f
+    assert list(ctr) == [int(x) for x in ref_ctr[:4]]
+    assert ref_ctr[1] / n > 3.0  # several instances entered per ray: the TLAS does real work here
+    assert np.array_equal(occ, ora.trace_any(desc, rays, nthreads=8))
+    assert gpu_ctx.stats().stack_drops == 0
+
+
+def test_bounce_rays_of_the_scene_match_oracle(pt, ora, gpu_ctx, devbuf, scene_factory):
+    """The scene's own secondary rays (mirror helmets, diffuse spheres): captured from the wavefront
+    pipeline at 256x144 and traced against the oracle."""
+    w, h = 256, 144
+    hs = scene_factory(SCENE, w, h, 8)
+    desc = hs.desc()
+    gpu_ctx.upload(desc)
+    gpu_ctx.integrator_init(w, h)
+    buf = devbuf(w * h * 32)
+    total = 0
+    for bounce in (1, 2, 3):
+        n = gpu_ctx.capture_bounce_rays(w, h, 0, bounce, buf.ptr, w * h)
+        assert n > 100
+        rays = buf.download(pt.abi.RAY, n)
+        hits = gpu_ctx.trace_closest_host(rays)
+        ref = ora.trace_closest(desc, rays, nthreads=8)
+        assert np.array_equal(hits["prim"], ref["prim"]) and np.array_equal(hits["inst"], ref["inst"])
+        assert np.array_equal(hits["t"].view(np.uint32), ref["t"].view(np.uint32))
+        total += n
+    assert total > 20000
+
+
+def test_one_sample_film_matches_oracle(pt, ora, gpu_ctx, party):
+    w, h = 128, 72
+    desc = party.desc()
+    gpu_ctx.upload(desc)
+    gpu_ctx.integrator_init(w, h)
+    gpu_ctx.reset_stats()
+    ref = None
+    for it in range(2):
+        gpu_ctx.render(w, h, it)
+        ref, _ = ora.render(desc, w, h, it, ref, nthreads=8)
+    film = gpu_ctx.film_download(w, h)
+    assert np.isfinite(film).all() and ref.mean() > 1e-3
+    close = (np.abs(film - ref) <= 1e-4 + 1e-3 * np.abs(ref)).all(axis=2)
+    assert close.mean() >= 0.97, f"only {close.mean():.4f} of the pixels agree"
+    st = gpu_ctx.stats()
+    assert st.nan_pixels == 0 and st.stack_drops == 0
+
+
+def test_device_bvh_build_is_bit_exact_at_20001_instances(pt, gpu_ctx, party):
+    """BLAS + TLAS built on the GPU equal the sequential host builder's arrays byte for byte
+    (bvh.cpp:5-332), including the O(n^2) agglomerative TLAS over 20 001 instance boxes."""
+    arr = party.arrays()
+    dev = gpu_ctx.bvh_build(arr["positions"], arr["indices"], arr["geometries"])
+    for key in ("tlas_nodes", "blases", "blas_nodes", "tri_indices"):
+        assert dev[key].tobytes() == arr[key].tobytes(), key
+
+
+def test_4k_frame_properties(pt, gpu_ctx, devbuf, scene_factory):
+    """3840x2160, the configuration's own resolution, one GPU: two samples in one pass, twice."""
+    w, h = 3840, 2160
+    hs = scene_factory(SCENE, w, h, 8)
+    gpu_ctx.upload(hs.desc())
+    gpu_ctx.integrator_init(w, h)
+    films, counts = [], []
+    for _ in range(2):
+        gpu_ctx.reset_stats()
+        gpu_ctx.render_batch(w, h, 0, 2)
+        gpu_ctx.synchronize()
+        st = gpu_ctx.stats()
+        assert st.paths == 2 * w * h and st.nan_pixels == 0 and st.stack_drops == 0
+        counts.append((int(st.closest_rays), int(st.shadow_rays), list(st.queue_sizes[:8])))
+        films.append(gpu_ctx.film_download(w, h))
+    assert counts[0] == counts[1], counts
+    assert counts[0][2][0] == 2 * w * h and counts[0][2][1] > w * h  # most camera rays hit something and go on
+    assert np.isfinite(films[0]).all() and films[0].mean() > 1e-3
+    assert np.array_equal(films[0].view(np.uint32), films[1].view(np.uint32))
+    gpu_ctx.integrator_destroy()  # 3 GB of path state: give it back before the next test
