@@ -16,7 +16,8 @@
 //   bit31 = 1, TLAS    leaf: bits[30:0] = GeometryInstance index
 //   bit31 = 1, BLAS    leaf: bits[30:28] = triangle count - 1 (0..6) and bits[27:0] = first DTri,
 //                      or bits[30:28] = 7 and bits[27:0] = index into big_leaves {first, count}
-//   0x7FFFFFFF         "nothing" (used inside the traversal loop)
+//   0x7FFFFFFF         "nothing" (used inside the traversal loop; an absent child of a 4-wide node)
+// The 4-wide layout of trace mode 2 (DNode4) uses the same references; interior ones index its own array.
 #pragma once
 #include "../../include/ptamd.h"
 #include "dmath.h"
@@ -32,6 +33,14 @@ struct DNode {
     float4 b;  // left  max.xyz, w = right ref bits
     float4 c;  // right min.xyz
     float4 d;  // right max.xyz
+};
+// 4-wide node (trace modes 2 and 3), 128 B = one cache line: the fp32 boxes of four children, stored by
+// axis so that one 16-byte load brings the same bound of all four, and the four child references.
+// An absent child has NaN bounds (every comparison of the slab test fails) and the reference kNoRef.
+struct DNode4 {
+    float4 lo_x, hi_x, lo_y, hi_y, lo_z, hi_z;  // component k belongs to child k
+    float4 refs;                                // bits: child references
+    float4 _pad;
 };
 struct DTri {
     float4 a;  // p0.xyz, p1.x
@@ -110,6 +119,8 @@ struct DCamera {
 
 struct DScene {
     const DNode *nodes;
+    const DNode4 *nodes4;         // the same trees collapsed to 4-wide nodes (trace mode 2)
+    const uint32_t *inst_root4;   // per instance: reference of its BLAS root in nodes4
     const DTri *tris;
     const DInst *insts;
     const DInstFwd *fwd;
@@ -129,6 +140,7 @@ struct DScene {
     uint32_t tex1_count, tex3_count, image1_count, image3_count;
     uint32_t light_count, material_count, geometry_count;
     uint32_t root_ref;
+    uint32_t root_ref4;           // TLAS root in nodes4
     float root_min[3], root_max[3];
     uint32_t max_depth;
     uint32_t any_hit_culls_with_tmax;  // trace mode 1: any-hit searches skip boxes that start beyond the ray's t_max

@@ -114,11 +114,7 @@ struct ClosestIO {
     }
     template <class TR>
     PTD void done(uint32_t i, uint32_t, const TR &tr, bool hit) const {
-        int prim = -1, mat = -1;
-        if (hit) {
-            prim = int(as_u(reinterpret_cast<const float4 *>(S.tris + tr.hit.rec)[2].y));
-            mat = int(as_u(reinterpret_cast<const float4 *>(S.insts + tr.hit.inst)[3].y));
-        }
+        const int prim = hit ? int(tr.hit.prim) : -1, mat = hit ? int(tr.hit.mat) : -1;
         float4 *hp = reinterpret_cast<float4 *>(hits + i);
         hp[0] = make_float4(hit ? tr.hit.t : -1.0f, hit ? tr.hit.u : 0.0f, hit ? tr.hit.v : 0.0f, as_f(uint32_t(prim)));
         hp[1] = make_float4(as_f(uint32_t(hit ? tr.hit.inst : -1)), as_f(uint32_t(mat)), 0.0f, 0.0f);
@@ -129,7 +125,7 @@ struct ClosestIO {
     PTD void finish() const {}
 };
 
-template <bool COUNT>
+template <bool COUNT, bool WIDE = false>
 __global__ __launch_bounds__(64) void k_trace_closest(DScene S, const pt_ray *rays, uint32_t n, pt_hit *hits, uint32_t *cursors, uint32_t cursor_count,
                                                       uint2 *spill, uint32_t spill_stride, DevStats *stats, TraceCounters *counters) {
     LaneEvents ev;
@@ -137,7 +133,7 @@ __global__ __launch_bounds__(64) void k_trace_closest(DScene S, const pt_ray *ra
     __shared__ unsigned long long lds[kWaveLdsEntries];
     const auto stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
     PT_WAVE_TIME(0);
-    trace_stream<MODE_CLOSEST, COUNT>(S, io, n, make_feed(cursors, cursor_count, n), stk, ev);
+    trace_stream<MODE_CLOSEST, COUNT, WIDE>(S, io, n, make_feed(cursors, cursor_count, n), stk, ev);
     PT_WAVE_TIME(1);
     flush_events(stats, ev);
 }
@@ -160,13 +156,14 @@ struct AnyIO {
     PTD void finish() const {}
 };
 
+template <bool WIDE = false>
 __global__ __launch_bounds__(64) void k_trace_any(DScene S, const pt_ray *rays, uint32_t n, uint8_t *occluded, uint32_t *cursors, uint32_t cursor_count,
                                                   uint2 *spill, uint32_t spill_stride, DevStats *stats) {
     LaneEvents ev;
     AnyIO io{rays, occluded};
     __shared__ unsigned long long lds[kWaveLdsEntries];
     const auto stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
-    trace_stream<MODE_ANY, false>(S, io, n, make_feed(cursors, cursor_count, n), stk, ev);
+    trace_stream<MODE_ANY, false, WIDE>(S, io, n, make_feed(cursors, cursor_count, n), stk, ev);
     flush_events(stats, ev);
 }
 
@@ -321,7 +318,7 @@ struct ExtendIO {
             return;
         }
         P.hit[slot] = make_float4(as_f(uint32_t(tr.hit.inst)), tr.hit.u, tr.hit.v, as_f(tr.hit.rec));
-        const uint32_t type = as_u(reinterpret_cast<const float4 *>(S.insts + tr.hit.inst)[3].z);
+        const uint32_t type = tr.hit.type;
         pend_cls = type == PT_MAT_LAMBERTIAN ? 1 : type == PT_MAT_MIRROR ? 2 : type == PT_MAT_METALLIC_ROUGHNESS ? 3
                    : type == PT_MAT_DIELECTRIC ? 4 : 0;
         pend_slot = slot;
@@ -371,6 +368,7 @@ struct ExtendIO {
     }
 };
 
+template <bool WIDE = false>
 __global__ __launch_bounds__(64) void k_extend(DScene S, PathState P, BounceCounters *cnt, int bounce, int width, int height, uint2 *spill,
                                                uint32_t spill_stride, DevStats *stats) {
     BounceCounters *bc = cnt + bounce;
@@ -378,9 +376,10 @@ __global__ __launch_bounds__(64) void k_extend(DScene S, PathState P, BounceCoun
     __shared__ uint32_t stage[kNumClasses * kStageCap];
     ExtendIO io{S, P, bc, bounce == 0 ? nullptr : P.ext_q[bounce & 1], width, height};
     io.stage = stage;
-    __shared__ unsigned long long lds[wave_lds_entries<kRenderLdsDepth>()];
-    const auto stk = make_lane_stack<kRenderLdsDepth>(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
-    trace_stream<MODE_CLOSEST, false>(S, io, bc->ext_count, make_feed(&bc->cur_extend, 1u, bc->ext_count), stk, ev);
+    constexpr int kDepth = WIDE ? kRenderLdsDepthWide : kRenderLdsDepth;
+    __shared__ unsigned long long lds[wave_lds_entries<kDepth>()];
+    const auto stk = make_lane_stack<kDepth>(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
+    trace_stream<MODE_CLOSEST, false, WIDE>(S, io, bc->ext_count, make_feed(&bc->cur_extend, 1u, bc->ext_count), stk, ev);
     flush_events(stats, ev);
 }
 
@@ -755,14 +754,16 @@ struct ShadowIO {
     PTD void finish() const {}
 };
 
+template <bool WIDE = false>
 __global__ __launch_bounds__(64) void k_shadow(DScene S, PathState P, BounceCounters *cnt, int bounce, uint2 *spill,
                                                uint32_t spill_stride, DevStats *stats) {
     BounceCounters *bc = cnt + bounce;
     LaneEvents ev;
     ShadowIO io{P};
-    __shared__ unsigned long long lds[wave_lds_entries<kRenderLdsDepth>()];
-    const auto stk = make_lane_stack<kRenderLdsDepth>(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
-    trace_stream<MODE_ANY, false>(S, io, bc->shadow_count, make_feed(&bc->cur_shadow, 1u, bc->shadow_count), stk, ev);
+    constexpr int kDepth = WIDE ? kRenderLdsDepthWide : kRenderLdsDepth;
+    __shared__ unsigned long long lds[wave_lds_entries<kDepth>()];
+    const auto stk = make_lane_stack<kDepth>(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
+    trace_stream<MODE_ANY, false, WIDE>(S, io, bc->shadow_count, make_feed(&bc->cur_shadow, 1u, bc->shadow_count), stk, ev);
     flush_events(stats, ev);
 }
 

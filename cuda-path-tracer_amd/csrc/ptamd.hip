@@ -15,6 +15,7 @@
 #include "kernels.h"
 #include "debug_view.h"
 #include "bvh_build.h"
+#include "wide_bvh.h"
 #ifndef PT_WAVES_PER_CU
 #define PT_WAVES_PER_CU 16  // persistent waves per CU (4 per SIMD) of a ray query
 #endif
@@ -535,6 +536,16 @@ int pt_debug_phase_prof(unsigned long long *out16) {
 }
 #endif
 
+#ifdef PT_TRACE_STAMPS
+// Diagnostic build only: reads and clears the clock totals of the traversal loop's parts.
+int pt_debug_trace_stamps(unsigned long long *out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(ptd::g_trace_stamps), 8 * sizeof(unsigned long long)) != hipSuccess) return PT_ERR_DEVICE;
+    unsigned long long zero[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_trace_stamps), zero, sizeof(zero)) != hipSuccess) return PT_ERR_DEVICE;
+    return PT_OK;
+}
+#endif
+
 #ifdef PT_WAVE_TIMES
 // Diagnostic build only: (start, end) clock pairs of the waves of the last closest-hit query.
 int pt_debug_wave_times(unsigned long long *out, unsigned waves) {
@@ -546,9 +557,9 @@ int pt_debug_wave_times(unsigned long long *out, unsigned waves) {
 
 int pt_set_trace_mode(pt_ctx *ctx, int mode) {
     if (!ctx) return PT_ERR_INVALID;
-    if (mode != 0 && mode != 1) return Fail(ctx, PT_ERR_INVALID, "trace mode %d (0 = reference-exact, 1 = any-hit culls boxes with t_max)", mode);
+    if (mode < 0 || mode > 3) return Fail(ctx, PT_ERR_INVALID, "trace mode %d (bit 0: any-hit culls boxes with t_max, bit 1: 4-wide BVH)", mode);
     ctx->trace_mode = mode;
-    ctx->scene.any_hit_culls_with_tmax = mode == 1 ? 1u : 0u;
+    ctx->scene.any_hit_culls_with_tmax = (mode & 1) ? 1u : 0u;
     return PT_OK;
 }
 
@@ -691,6 +702,7 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
 
     std::vector<uint32_t> blas_root(d->blas_count, kNoRef);
     std::vector<uint32_t> node_map(d->blas_node_count, kNoRef);
+    std::vector<uint32_t> leaf_ref(d->blas_node_count, kNoRef);  // reference word of every BLAS leaf, shared by both node layouts
     for (uint32_t b = 0; b < d->blas_count; ++b) {
         const pt_blas &blas = d->blases[b];
         if (blas.node_count == 0) continue;
@@ -699,11 +711,11 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
                 node_map[k] = uint32_t(nodes.size());
                 nodes.emplace_back();
             }
-        auto ref_of = [&](uint32_t k) -> uint32_t {
+        for (uint32_t k = blas.first_node; k < blas.first_node + blas.node_count; ++k) {
             const pt_bvh_node &n = d->blas_nodes[k];
-            if (n.primitive_count > 0) return EncodeLeaf(blas.first_index + n.first_primitive, n.primitive_count, big_leaves);
-            return node_map[k];
-        };
+            if (n.primitive_count > 0) leaf_ref[k] = EncodeLeaf(blas.first_index + n.first_primitive, n.primitive_count, big_leaves);
+        }
+        auto ref_of = [&](uint32_t k) -> uint32_t { return d->blas_nodes[k].primitive_count > 0 ? leaf_ref[k] : node_map[k]; };
         for (uint32_t k = blas.first_node; k < blas.first_node + blas.node_count; ++k) {
             const pt_bvh_node &n = d->blas_nodes[k];
             if (n.primitive_count > 0) continue;
@@ -716,6 +728,43 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
         blas_root[b] = ref_of(blas.first_node);
     }
     if (nodes.size() >= kNoRef) return Fail(ctx, PT_ERR_LIMIT, "too many BVH nodes");
+
+    // ---- the same trees as 4-wide nodes with quantised boxes (trace mode 2)
+    std::vector<DNode4> nodes4;
+    struct BlasTree {
+        const pt_bvh_node *n;
+        const uint32_t *leaf_refs;
+        bool is_leaf(uint32_t i) const { return n[i].primitive_count > 0; }
+        uint32_t left(uint32_t i) const { return n[i].first_primitive; }
+        uint32_t right(uint32_t i) const { return n[i].first_primitive + 1; }
+        ptw::Box box(uint32_t i) const { return ptw::Box{{n[i].min[0], n[i].min[1], n[i].min[2]}, {n[i].max[0], n[i].max[1], n[i].max[2]}}; }
+        uint32_t leaf_ref(uint32_t i) const { return leaf_refs[i]; }
+    };
+    // the top level is rebuilt over the reference's TLAS leaves (instance world boxes, bvh.cpp:273-280)
+    std::vector<ptw::Box> inst_boxes;
+    std::vector<uint32_t> inst_ids;
+    for (uint32_t i = 0; i < d->tlas_node_count; ++i) {
+        const pt_tlas_node &n = d->tlas_nodes[i];
+        if (n.left_right != 0 || (i == 0 && d->tlas_node_count > 1)) continue;  // interior node, or the root's copy of a lone leaf
+        inst_boxes.push_back(ptw::Box{{n.min[0], n.min[1], n.min[2]}, {n.max[0], n.max[1], n.max[2]}});
+        inst_ids.push_back(n.instance);
+    }
+    const ptw::TopLevel top = ptw::BuildTopLevel(inst_boxes.data(), uint32_t(inst_boxes.size()));
+    struct TopTree {
+        const ptw::TopLevel *t;
+        const uint32_t *ids;
+        bool is_leaf(uint32_t i) const { return t->nodes[i].left == 0xFFFFFFFFu; }
+        uint32_t left(uint32_t i) const { return t->nodes[i].left; }
+        uint32_t right(uint32_t i) const { return t->nodes[i].right; }
+        ptw::Box box(uint32_t i) const { return t->nodes[i].box; }
+        uint32_t leaf_ref(uint32_t i) const { return kLeafBit | ids[t->nodes[i].item]; }
+    };
+    const uint32_t root_ref4 = top.nodes.empty() ? root_ref : ptw::Collapse(TopTree{&top, inst_ids.data()}, 0u, nodes4);
+    std::vector<uint32_t> blas_root4(d->blas_count, kNoRef);
+    for (uint32_t b = 0; b < d->blas_count; ++b)
+        if (d->blases[b].node_count > 0) blas_root4[b] = ptw::Collapse(BlasTree{d->blas_nodes, leaf_ref.data()}, d->blases[b].first_node, nodes4);
+    std::vector<uint32_t> inst_root4(d->geometry_count);
+    for (uint32_t i = 0; i < d->geometry_count; ++i) inst_root4[i] = blas_root4[d->geometries[i].blas_index];
 
     // ---- instances
     std::vector<DInst> insts(d->geometry_count);
@@ -909,6 +958,9 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
     UP(light_tris, light_tris);
     if (nodes.empty()) nodes.emplace_back();  // lanes without work read record 0 of this array
     UP(nodes, nodes);
+    if (nodes4.empty()) nodes4.emplace_back();
+    UP(nodes4, nodes4);
+    UP(inst_root4, inst_root4);
     UP(tris, tris);
     UP(insts, insts);
     UP(fwd, fwd);
@@ -933,12 +985,13 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
     S.material_count = d->material_count;
     S.geometry_count = d->geometry_count;
     S.root_ref = root_ref;
+    S.root_ref4 = root_ref4;
     for (int a = 0; a < 3; ++a) {
         S.root_min[a] = d->tlas_nodes[0].min[a];
         S.root_max[a] = d->tlas_nodes[0].max[a];
     }
     S.max_depth = d->max_depth;
-    S.any_hit_culls_with_tmax = ctx->trace_mode == 1 ? 1u : 0u;
+    S.any_hit_culls_with_tmax = (ctx->trace_mode & 1) ? 1u : 0u;
     S.total_light_power = d->total_light_power;
     FillCamera(S.camera, d->camera);
     ctx->scene_ready = true;
@@ -1065,6 +1118,7 @@ static int RunBounces(pt_ctx *ctx, pt_ctx::Lane &l, hipStream_t stream, int widt
         hipLaunchKernelGGL(k_generate, dim3(tiles), dim3(kWave), 0, stream, S, P, l.counters, iteration, width, height);
     }
     const dim3 block(kWave);
+    const bool wide = (ctx->trace_mode & 2) != 0;
     const dim3 grid_extend(ctx->render_blocks[0]), grid_shade(ctx->render_blocks[1]), grid_shadow(ctx->render_blocks[2]);
     ctx->last_render_bounces = bounces;
     for (int b = 0; b < bounces; ++b) {
@@ -1072,7 +1126,8 @@ static int RunBounces(pt_ctx *ctx, pt_ctx::Lane &l, hipStream_t stream, int widt
         if (last && !shade_last) break;
         {
             ScopedEvent ev(timed ? ctx : nullptr, EV_CLOSEST);
-            hipLaunchKernelGGL(k_extend, grid_extend, block, 0, stream, S, P, l.counters, b, width, height, l.spill, ctx->spill_stride, ctx->dev_stats);
+            if (wide) hipLaunchKernelGGL(k_extend<true>, grid_extend, block, 0, stream, S, P, l.counters, b, width, height, l.spill, ctx->spill_stride, ctx->dev_stats);
+            else hipLaunchKernelGGL(k_extend<false>, grid_extend, block, 0, stream, S, P, l.counters, b, width, height, l.spill, ctx->spill_stride, ctx->dev_stats);
         }
         {
             ScopedEvent ev(timed ? ctx : nullptr, EV_SHADE);
@@ -1080,7 +1135,8 @@ static int RunBounces(pt_ctx *ctx, pt_ctx::Lane &l, hipStream_t stream, int widt
         }
         {
             ScopedEvent ev(timed ? ctx : nullptr, EV_ANY);
-            hipLaunchKernelGGL(k_shadow, grid_shadow, block, 0, stream, S, P, l.counters, b, l.spill, ctx->spill_stride, ctx->dev_stats);
+            if (wide) hipLaunchKernelGGL(k_shadow<true>, grid_shadow, block, 0, stream, S, P, l.counters, b, l.spill, ctx->spill_stride, ctx->dev_stats);
+            else hipLaunchKernelGGL(k_shadow<false>, grid_shadow, block, 0, stream, S, P, l.counters, b, l.spill, ctx->spill_stride, ctx->dev_stats);
         }
         // Long depth limits: stop launching once the extension queue has drained.  Only a call that blocks
         // the host anyway (pt_render, the ray captures) reads the counter back for that; an asynchronous
@@ -1290,8 +1346,12 @@ int pt_trace_closest(pt_ctx *ctx, const pt_ray *rays, size_t n, pt_hit *hits) {
     const uint32_t blocks = uint32_t(std::min<size_t>(ctx->grid_blocks, (n + kWave - 1) / kWave));
     {
         ScopedEvent ev(ctx, EV_CLOSEST);
-        hipLaunchKernelGGL(k_trace_closest<false>, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors,
-                           ctx->lane[0].spill, ctx->spill_stride, ctx->dev_stats, static_cast<TraceCounters *>(nullptr));
+        if (ctx->trace_mode & 2)
+            hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors,
+                               ctx->lane[0].spill, ctx->spill_stride, ctx->dev_stats, static_cast<TraceCounters *>(nullptr));
+        else
+            hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors,
+                               ctx->lane[0].spill, ctx->spill_stride, ctx->dev_stats, static_cast<TraceCounters *>(nullptr));
     }
     HIP_TRY(ctx, hipGetLastError());
     return PT_OK;
@@ -1313,8 +1373,12 @@ int pt_trace_closest_static(pt_ctx *ctx, const pt_ray *rays, size_t n, pt_hit *h
     // cursors and counters start at zero; the spill area is written before it is read
     HIP_TRY(ctx, hipMemsetAsync(base, 0, kStaticSpillOffset, ctx->stream));
     const uint32_t blocks = uint32_t(std::min<size_t>(std::min<uint32_t>(ctx->grid_blocks, kStaticWaves), (n + kWave - 1) / kWave));
-    hipLaunchKernelGGL(k_trace_closest<false>, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, cursors, ctx->query_cursors, spill,
-                       kStaticWaves * uint32_t(kWave), stats, static_cast<TraceCounters *>(nullptr));
+    if (ctx->trace_mode & 2)
+        hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, cursors, ctx->query_cursors, spill,
+                           kStaticWaves * uint32_t(kWave), stats, static_cast<TraceCounters *>(nullptr));
+    else
+        hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, cursors, ctx->query_cursors, spill,
+                           kStaticWaves * uint32_t(kWave), stats, static_cast<TraceCounters *>(nullptr));
     HIP_TRY(ctx, hipGetLastError());
     return PT_OK;
 }
@@ -1328,8 +1392,12 @@ int pt_trace_any(pt_ctx *ctx, const pt_ray *rays, size_t n, uint8_t *occluded) {
     const uint32_t blocks = uint32_t(std::min<size_t>(ctx->grid_blocks, (n + kWave - 1) / kWave));
     {
         ScopedEvent ev(ctx, EV_ANY);
-        hipLaunchKernelGGL(k_trace_any, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), occluded, ctx->cursor, ctx->query_cursors, ctx->lane[0].spill,
-                           ctx->spill_stride, ctx->dev_stats);
+        if (ctx->trace_mode & 2)
+            hipLaunchKernelGGL(k_trace_any<true>, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), occluded, ctx->cursor, ctx->query_cursors, ctx->lane[0].spill,
+                               ctx->spill_stride, ctx->dev_stats);
+        else
+            hipLaunchKernelGGL(k_trace_any<false>, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), occluded, ctx->cursor, ctx->query_cursors, ctx->lane[0].spill,
+                               ctx->spill_stride, ctx->dev_stats);
     }
     HIP_TRY(ctx, hipGetLastError());
     return PT_OK;
@@ -1355,8 +1423,12 @@ int pt_trace_closest_counted(pt_ctx *ctx, const pt_ray *rays, size_t n, pt_hit *
     HIP_TRY(ctx, Join(ctx));  // lane 0's spill area is shared with render passes
     HIP_TRY(ctx, hipMemsetAsync(ctx->cursor, 0, size_t(ctx->query_cursors) * kCursorStride * sizeof(uint32_t), ctx->stream));
     const uint32_t blocks = uint32_t(std::min<size_t>(ctx->grid_blocks, (n + kWave - 1) / kWave));
-    hipLaunchKernelGGL(k_trace_closest<true>, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors, ctx->lane[0].spill,
-                       ctx->spill_stride, ctx->dev_stats, reinterpret_cast<TraceCounters *>(counters4));
+    if (ctx->trace_mode & 2)
+        hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors, ctx->lane[0].spill,
+                           ctx->spill_stride, ctx->dev_stats, reinterpret_cast<TraceCounters *>(counters4));
+    else
+        hipLaunchKernelGGL((k_trace_closest<true, false>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors, ctx->lane[0].spill,
+                           ctx->spill_stride, ctx->dev_stats, reinterpret_cast<TraceCounters *>(counters4));
     HIP_TRY(ctx, hipGetLastError());
     return PT_OK;
 }

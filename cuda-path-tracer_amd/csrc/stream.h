@@ -30,7 +30,40 @@
 
 namespace ptd {
 
-template <int MODE, bool COUNT, int DEPTH = kLdsDepth>
+// Diagnostic build only (-DPT_TRACE_STAMPS): wave clock spent in the parts of the traversal loop, every
+// stamp first waiting for all outstanding memory operations (so the waits are attributed to the part
+// that issued them).  0 box round: votes + load issue + pop, 1 box round: wait for the node,
+// 2 box round: box tests + push, 3 triangle rounds, 4 enter / level rounds, 5 refill, 6 rounds counted.
+#ifdef PT_TRACE_STAMPS
+__device__ unsigned long long g_trace_stamps[8];
+#define PT_TSTAMP(k)                                                                                         \
+    do {                                                                                                     \
+        unsigned long long t_;                                                                               \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+        tstamp_acc[k] += t_ - tstamp_last;                                                                   \
+        tstamp_last = t_;                                                                                    \
+    } while (0)
+#define PT_TSTAMP_NOWAIT(k)                                                                                  \
+    do {                                                                                                     \
+        unsigned long long t_;                                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                             \
+        tstamp_acc[k] += t_ - tstamp_last;                                                                   \
+        tstamp_last = t_;                                                                                    \
+    } while (0)
+#else
+#define PT_TSTAMP(k) do { } while (0)
+#define PT_TSTAMP_NOWAIT(k) do { } while (0)
+#endif
+
+// WIDE (trace modes 2 and 3) walks 4-wide nodes (DNode4) instead of the binary ones: half as many
+// dependent node visits, one 128-byte line for four children.  The boxes are the reference's and are
+// tested with its arithmetic, so a box is entered here exactly when its own test passes in the binary
+// tree; what differs is the visiting order, so exact ties (equal distances) may pick another
+// triangle, and the winner's distance and barycentrics come from the same triangle test on the same
+// record.  The wide layout also spends what the reference leaves on the table: inside an instance
+// the search is bounded by the best hit of the instances before it (object-space and world-space
+// distances are the same quantity, math/ray.h:19-21).
+template <int MODE, bool COUNT, int DEPTH = kLdsDepth, bool WIDE = false>
 struct Traversal {
     V3 o, d, iw;     // world-space ray and reciprocal direction
     V3 co, cd, ci;   // ray in the current space (world, or the current instance's object space)
@@ -38,8 +71,10 @@ struct Traversal {
     float best;      // best world-space distance over finished instances
     float cbest;     // culling bound of the current level: `best` in the TLAS, the instance's own
                      // best object-space distance inside a BLAS; the ray's t_max in MODE_ANY
-    uint32_t lrec;
+    uint32_t lrec, lprim;
     float lu, lv;
+    uint32_t cur_mat, cur_type;  // of the instance being searched
+    bool lfound;     // WIDE: the current instance has produced a candidate
     int cur_inst;
     int sp, base;
     bool in_blas;
@@ -60,6 +95,7 @@ struct Traversal {
         hit.u = hit.v = 0.0f;
         hit.rec = 0;
         hit.inst = -1;
+        hit.prim = hit.mat = hit.type = 0xFFFFFFFFu;
         found = false;
         if (COUNT) {
             ctr = TraceCounters{0, 0, 0, 0};
@@ -77,11 +113,12 @@ struct Traversal {
         cbest = (MODE == MODE_ANY && S.any_hit_culls_with_tmax) ? t_max : FLT_MAX;
         lrec = 0;
         lu = lv = 0.0f;
+        lfound = false;
         cur_inst = -1;
         sp = 0;
         base = 0;
         in_blas = false;
-        cur = S.root_ref;
+        cur = WIDE ? S.root_ref4 : S.root_ref;
         tri_next = tri_left = 0;
         held = kNoRef;
         return true;
@@ -198,6 +235,65 @@ struct Traversal {
         }
     }
 
+    // One 4-wide node (trace modes 2 and 3): four slab tests with the reference's arithmetic and
+    // acceptance rule (math/intersection.h:9-35) on the reference's own boxes, so each box decides as
+    // it does in the binary tree; the children that are hit are ordered by entry distance, the nearest
+    // is visited next and the others are pushed, farthest first.
+    static PTD void order(uint32_t &ka, uint32_t &ra, uint32_t &kb, uint32_t &rb) {
+        const bool swap = kb < ka;
+        const uint32_t lo = swap ? kb : ka, hi = swap ? ka : kb;
+        const uint32_t rlo = swap ? rb : ra, rhi = swap ? ra : rb;
+        ka = lo; kb = hi; ra = rlo; rb = rhi;
+    }
+    static PTD float comp(const float4 &v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
+    template <class STK>
+    PTD void op_interior4(const STK &stk, LaneEvents &ev, const float4 (&q)[7]) {
+        if (COUNT) {
+            ctr.interior++;
+            if (!in_blas) tlas_interior++;
+        }
+        constexpr uint32_t kMiss = 0x7F800000u;  // +inf: sorts behind every hit
+        uint32_t key[4], ref[4] = {as_u(q[6].x), as_u(q[6].y), as_u(q[6].z), as_u(q[6].w)};
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float tn;
+            const bool hit = slab(co, ci, comp(q[0], k), comp(q[2], k), comp(q[4], k), comp(q[1], k), comp(q[3], k), comp(q[5], k), cbest, tn);
+            n += hit ? 1 : 0;
+            // the entry distance, clamped at the origin (as an integer: the bits of a negative float are a
+            // negative integer) and rounded down to make room for the slot number that makes the keys distinct
+            const int bits = int(as_u(tn));
+            key[k] = hit ? ((uint32_t(bits < 0 ? 0 : bits) & ~3u) | uint32_t(k)) : (kMiss | uint32_t(k));
+        }
+        order(key[0], ref[0], key[1], ref[1]);
+        order(key[2], ref[2], key[3], ref[3]);
+        order(key[0], ref[0], key[2], ref[2]);
+        order(key[1], ref[1], key[3], ref[3]);
+        order(key[1], ref[1], key[2], ref[2]);
+        cur = n > 0 ? ref[0] : kNoRef;
+        // Usual case, decided for the wave: every lane has room for three more entries in the LDS part
+        // of its stack.  Then all three candidates are stored without a branch: child j of the sorted
+        // list belongs at sp + n - 1 - j, and the ones that were not hit land above the new top.
+        const bool rare = sp + 3 >= DEPTH;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) == 0, 1)) {
+#pragma unroll
+            for (int j = 1; j < 4; ++j) stk.lds[(sp + ((n - 1 - j) & 3)) * kWave] = ((unsigned long long)key[j] << 32) | ref[j];
+            sp += n > 1 ? n - 1 : 0;
+            return;
+        }
+#pragma unroll
+        for (int j = 3; j >= 1; --j) {
+            if (j < n) {
+                if (sp < DEPTH + kSpillDepth) {
+                    stack_store(stk, sp, ref[j], as_f(key[j]), ev);
+                    ++sp;
+                } else {
+                    ev.drops++;  // the physical stack is full: the subtree is lost (counted in pt_stats.stack_drops)
+                }
+            }
+        }
+    }
+
     // TLAS leaf: enter the instance (kernel/intersection.h:183-188, :37-50).
     PTD void op_enter(const DScene &S) {
         if (COUNT) ctr.tlas_leaves++;
@@ -212,10 +308,13 @@ struct Traversal {
         co = xform(inv, o, 1.0f);
         cd = xform(inv, d, 0.0f);
         ci = mk3(1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z);
-        if (MODE == MODE_CLOSEST) cbest = FLT_MAX;
+        if (MODE == MODE_CLOSEST) cbest = WIDE ? best : FLT_MAX;
+        lfound = false;
         base = sp;
         in_blas = true;
-        cur = as_u(in.d.x);
+        cur = WIDE ? S.inst_root4[cur_inst] : as_u(in.d.x);
+        cur_mat = as_u(in.d.y);
+        cur_type = as_u(in.d.z);
         tri_left = 0;
     }
 
@@ -253,7 +352,9 @@ struct Traversal {
             }
         } else if (ok && t < cbest) {
             cbest = t;
+            lfound = true;
             lrec = tri_next;
+            lprim = as_u(tc.y);
             lu = u;
             lv = v;
         }
@@ -270,7 +371,7 @@ struct Traversal {
     PTD bool op_level(const DScene &S) {
         if (in_blas) {
             if (MODE == MODE_CLOSEST) {
-                if (cbest < FLT_MAX) {
+                if (WIDE ? lfound : cbest < FLT_MAX) {
                     const V3 lp = tri_point(S.tris, lrec, lu, lv);
                     const float4 *fp = reinterpret_cast<const float4 *>(S.fwd + cur_inst);
                     const M34 T = load_m34(fp[0], fp[1], fp[2]);
@@ -283,6 +384,9 @@ struct Traversal {
                         hit.v = lv;
                         hit.rec = lrec;
                         hit.inst = cur_inst;
+                        hit.prim = lprim;
+                        hit.mat = cur_mat;
+                        hit.type = cur_type;
                     }
                 }
                 cbest = best;
@@ -365,9 +469,9 @@ PTD bool fetch_rays(const WorkFeed &feed, uint32_t n, uint32_t &dry, uint32_t &b
     return true;
 }
 
-template <int MODE, bool COUNT, class IO, class STK>
+template <int MODE, bool COUNT, bool WIDE = false, class IO, class STK>
 PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed, const STK &stk, LaneEvents &ev) {
-    Traversal<MODE, COUNT, STK::kDepth> tr;
+    Traversal<MODE, COUNT, STK::kDepth, WIDE> tr;
     tr.cur = kNoRef;
     tr.in_blas = false;
     tr.sp = tr.base = 0;
@@ -376,7 +480,13 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform
     uint32_t dry = 0;                      // wave-uniform: cursors found empty
     bool exhausted = false;                // wave-uniform
-    const char *node_base = reinterpret_cast<const char *>(S.nodes);
+#ifdef PT_TRACE_STAMPS
+    unsigned long long tstamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tstamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstamp_last)::"memory");
+#endif
+    const char *node_base = WIDE ? reinterpret_cast<const char *>(S.nodes4) : reinterpret_cast<const char *>(S.nodes);
+    constexpr int kNodeShift = WIDE ? 7 : 6;  // 128-byte wide nodes, 64-byte binary ones
+    constexpr int kNodeRegs = WIDE ? 7 : 4;   // 16-byte words of a node that the box tests read
 #if PT_STAGE_RAYS
     // Rays are read 64 at a time, by all lanes together, into the wave's LDS, and handed to lanes as
     // they fall idle: the wave then waits for a gather from path state (thousands of cycles when the
@@ -460,6 +570,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
         const bool can_refill = !(exhausted && pool_next >= pool_end);  // wave-uniform
 #endif
         PT_PHASE(ev, 7);
+        PT_TSTAMP(5);
 
         // ---- box-test rounds, while enough lanes take part.  The node loads are issued before
         // the pops so that the LDS round trip hides behind them.
@@ -477,13 +588,11 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
             const unsigned long long int_mask = __builtin_amdgcn_ballot_w64(tr.wants_interior()) & active_mask;
             const bool w_int = active && tr.wants_interior();
             const bool go = __builtin_popcountll(int_mask) >= vote_int;
-            float4 na, nb, nc, nd;
+            float4 nq[kNodeRegs];
             if (go && w_int) {
-                const float4 *np = reinterpret_cast<const float4 *>(node_base + (size_t(tr.cur) << 6));
-                na = np[0];
-                nb = np[1];
-                nc = np[2];
-                nd = np[3];
+                const float4 *np = reinterpret_cast<const float4 *>(node_base + (size_t(tr.cur) << kNodeShift));
+#pragma unroll
+                for (int r = 0; r < kNodeRegs; ++r) nq[r] = np[r];
             }
 #ifndef PT_POP_FIRST
             if (active && tr.wants_pop()) {
@@ -491,11 +600,18 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
                 tr.pop(stk);
             }
 #endif
+            PT_TSTAMP_NOWAIT(0);
             if (!go) break;
+            PT_TSTAMP(1);
             if (w_int) {
                 PT_PHASE(ev, 0);
-                tr.op_interior(stk, ev, na, nb, nc, nd);
+                if constexpr (WIDE) tr.op_interior4(stk, ev, nq);
+                else tr.op_interior(stk, ev, nq[0], nq[1], nq[2], nq[3]);
             }
+            PT_TSTAMP(2);
+#ifdef PT_TRACE_STAMPS
+            tstamp_acc[6]++;
+#endif
         }
 
         // ---- the other operations, each only when enough lanes want it (or nothing else would run)
@@ -517,10 +633,15 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
         if (n_int == n_max || (drain && n_int > 0)) {  // fewer than PT_VOTE_INT lanes, but still the largest group
             if (w_int) {
                 PT_PHASE(ev, 0);
-                const float4 *np = reinterpret_cast<const float4 *>(node_base + (size_t(tr.cur) << 6));
-                tr.op_interior(stk, ev, np[0], np[1], np[2], np[3]);
+                const float4 *np = reinterpret_cast<const float4 *>(node_base + (size_t(tr.cur) << kNodeShift));
+                float4 nq[kNodeRegs];
+#pragma unroll
+                for (int r = 0; r < kNodeRegs; ++r) nq[r] = np[r];
+                if constexpr (WIDE) tr.op_interior4(stk, ev, nq);
+                else tr.op_interior(stk, ev, nq[0], nq[1], nq[2], nq[3]);
             }
         }
+        PT_TSTAMP(4);
         if (n_tri >= PT_VOTE_TRI || n_tri == n_max || (drain && n_tri > 0)) {
             do {
                 if (active && tr.wants_triangle()) {
@@ -531,8 +652,12 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
                     }
                 }
                 n_tri = count_lanes(active && tr.wants_triangle());
+#ifdef PT_TRACE_STAMPS
+                tstamp_acc[7]++;
+#endif
             } while (n_tri >= PT_VOTE_TRI);
         }
+        PT_TSTAMP(3);
         if (n_ent > 0 && (n_ent >= PT_VOTE_RARE || n_ent == n_max || drain)) {
             if (w_ent) {
                 PT_PHASE(ev, 1);
@@ -552,6 +677,11 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
     }
     io.flush();
     io.finish();
+#ifdef PT_TRACE_STAMPS
+    PT_TSTAMP(4);
+    if ((threadIdx.x & 63u) == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_trace_stamps[k], tstamp_acc[k]);
+#endif
 }
 
 }  // namespace ptd

@@ -39,6 +39,12 @@ constexpr int kLdsDepth = PT_LDS_DEPTH;  // stack entries per lane held in LDS b
 // LDS use (measured: 2 KB more per wave cost 4 % of the frame rate), so they keep fewer entries
 // in LDS and spill a little more often.
 constexpr int kRenderLdsDepth = PT_RENDER_LDS_DEPTH;
+#ifndef PT_RENDER_LDS_DEPTH_WIDE
+#define PT_RENDER_LDS_DEPTH_WIDE 12
+#endif
+// A 4-wide node pushes up to three entries at once and does so without a branch only while three
+// more entries fit the LDS part of the stack, so the render kernels of trace mode 2 keep a few more.
+constexpr int kRenderLdsDepthWide = PT_RENDER_LDS_DEPTH_WIDE;
 constexpr int kRefStack = 64;  // capacity of each of the reference's two stacks
 constexpr int kSpillDepth = 2 * kRefStack - (kLdsDepth < kRenderLdsDepth ? kLdsDepth : kRenderLdsDepth);  // sized for the shallower LDS part
 constexpr int kWave = 64;
@@ -79,6 +85,9 @@ struct HitRec {
     float t, u, v;
     uint32_t rec;  // DTri index of the hit
     int inst;      // GeometryInstance index, -1 = miss
+    // carried along from records the traversal reads anyway, so that finishing a ray needs no further gather:
+    uint32_t prim;      // the triangle's index inside its mesh (DTri::c.y)
+    uint32_t mat, type; // material id and material type of the instance (DInst::d.y, d.z)
 };
 
 struct TraceCounters {  // per-ray visit counts, filled only by the counting variants

@@ -348,7 +348,8 @@ class Context:
         self._check(self._lib.pt_synchronize(self._h))
 
     def set_trace_mode(self, mode: int):
-        """0 = reference-exact (default); 1 = any-hit searches skip boxes beyond the ray's t_max."""
+        """Two bits. 0 = reference-exact (default); bit 0: any-hit searches skip boxes beyond the ray's
+        t_max; bit 1: 4-wide BVH nodes, rebuilt top level, searches bounded across instances."""
         self._check(self._lib.pt_set_trace_mode(self._h, int(mode)))
 
     def set_profiling(self, on: bool):

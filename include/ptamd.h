@@ -435,10 +435,18 @@ int pt_capture_bounce_rays(pt_ctx *ctx, int width, int height, int iteration, in
 int pt_capture_shadow_rays(pt_ctx *ctx, int width, int height, int iteration, int bounce,
                            pt_ray *rays_device, size_t capacity, size_t *count);
 
-/* Traversal variant: 0 = reference-exact (default).  1 = any-hit searches (pt_trace_any, shadow
- * rays) skip boxes that start beyond the ray's t_max, which the reference does not do
- * (kernel/intersection.h:120-121,209-210 test child boxes against FLT_MAX): fewer nodes are
- * visited, and the occlusion flag can differ where a triangle lies within rounding of t_max.  */
+/* Traversal variant, two independent bits; 0 (default) answers every query exactly like the reference.
+ * Bit 0 (modes 1, 3): any-hit searches (pt_trace_any, shadow rays) skip boxes that start beyond the
+ *   ray's t_max, which the reference does not do (kernel/intersection.h:120-121,209-210 test child
+ *   boxes against FLT_MAX): fewer nodes are visited, and "occluded" can turn into "free" where a
+ *   triangle lies within rounding of t_max (never the other way round).
+ * Bit 1 (modes 2, 3): the trees are walked as 4-wide nodes (128 bytes: the reference's own fp32 boxes
+ *   of four children, tested with the reference's arithmetic), the top level is rebuilt top down over
+ *   the reference's instance boxes, and the search inside an instance is bounded by the best hit of
+ *   the instances visited before.  Every box decides as in the reference; the visiting order differs,
+ *   so rays with two triangles at the same distance may report the other one (same t to rounding;
+ *   all other rays get bit-identical records), and the 64-entry stack limit of the reference
+ *   (utils/stack.h:8-11) is not reproduced: deep trees are traversed completely.                  */
 int pt_set_trace_mode(pt_ctx *ctx, int mode);
 
 #ifdef __cplusplus

@@ -25,6 +25,13 @@ for it in range(2):
 rays = torch.cat(chunks)
 n = rays.numel() // 8
 hits = torch.empty(n * 8, dtype=torch.float32, device=dev)
+mode = int(os.environ.get("PT_TRACE_MODE", "0"))
+ctx.set_trace_mode(mode)
+ctr = torch.zeros(n * 4, dtype=torch.int32, device=dev)
+ctx.trace_closest_counted(rays.data_ptr(), n, hits.data_ptr(), ctr.data_ptr())
+ctx.synchronize()
+c = ctr.view(-1, 4).to(torch.int64).sum(dim=0).cpu().numpy() / n
+print(f"trace mode {mode}: per ray interior {c[0]:.2f}, instances entered {c[1]:.2f}, triangles {c[2]:.2f}, leaves {c[3]:.2f}")
 lib = pt.abi.load_library()
 out = (C.c_ulonglong * 16)()
 ctx.synchronize()
