@@ -10,6 +10,9 @@ resident in HBM before the timed region starts.  With N ranks every rank traces 
 shards iterations over ranks (rank r renders r, r+N, ...) and ends with one RCCL reduce of the
 fp32 film to rank 0, inside the timed region.
 
+`value` is the reference-exact traversal (trace mode 0).  The 4-wide traversal (trace mode 2) is
+timed on the same batch and reported beside it together with its id mismatches against mode 0.
+
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -17,7 +20,9 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -26,13 +31,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak
+STATE_BYTES = 184      # per path and bounce: the reference's PathSegments record (path_trace.h:24-80)
+# Dependent random 64-byte gathers from an L2 / MALL resident table top out at 210 G records/s on one
+# MI355X whatever the load shape (tools/ubench/gather_shapes.hip): the ceiling for node / triangle fetches.
+GATHER_CEILING_GBS = 210.0 * 64.0
 
 
-def algorithmic_bytes(n_rays: int, interior: int, tlas_leaves: int, tris: int) -> float:
-    """Layout-independent traffic of a closest-hit batch: per ray 32 B in + 16 B out + the root
-    and both children of every expanded interior node (32 B each) + a 3x4 matrix per instance
-    entered (48 B) + three fp32 positions per triangle tested (36 B)."""
-    return 48.0 * n_rays + 32.0 * (n_rays + 2.0 * interior) + 48.0 * tlas_leaves + 36.0 * tris
+def ray_bytes(n_rays, interior, tlas_leaves, tris, out_bytes):
+    """Layout-independent traffic of a ray batch: per ray 32 B in + `out_bytes` out + the root and both
+    children of every expanded interior node of the reference's binary BVH (32 B each) + a 3x4 matrix
+    per instance entered (48 B) + three fp32 positions per triangle tested (36 B)."""
+    return (32.0 + out_bytes) * n_rays + 32.0 * (n_rays + 2.0 * interior) + 48.0 * tlas_leaves + 36.0 * tris
+
+
+def split_line(ms, streamed_bytes, scene_bytes):
+    """A kernel's algorithmic bytes against what can bound them: the part that has to stream through HBM
+    (rays, hit records, path state, film) against the HBM peak, and the scene part (nodes, triangles,
+    instance matrices; L2 / MALL resident for every scene here) against the measured gather ceiling."""
+    sec = ms * 1e-3
+    streamed = streamed_bytes / sec / 1e9 if sec > 0 else 0.0
+    scene = scene_bytes / sec / 1e9 if sec > 0 else 0.0
+    return {"ms": ms, "streamed_bytes": streamed_bytes, "scene_bytes": scene_bytes, "achieved": streamed, "frac": streamed / HBM_PEAK_GBS,
+            "scene_gather_achieved": scene, "scene_gather_ceiling": GATHER_CEILING_GBS, "scene_gather_frac": scene / GATHER_CEILING_GBS}
 
 
 def main():
@@ -96,42 +116,66 @@ def main():
     n_rays = rays.numel() // 8
     hits = torch.empty(n_rays * 8, dtype=torch.float32, device=dev)
 
+    def visit_sums(rays_t, n, any_hit=False):
+        """Visit counters of a batch in the reference's binary BVH (trace mode 0), summed."""
+        counters = torch.zeros(n * 4, dtype=torch.int32, device=dev)
+        if any_hit:
+            occ = torch.empty(n, dtype=torch.uint8, device=dev)
+            ctx.trace_any_counted(rays_t.data_ptr(), n, occ.data_ptr(), counters.data_ptr())
+        else:
+            h = torch.empty(n * 8, dtype=torch.float32, device=dev)
+            ctx.trace_closest_counted(rays_t.data_ptr(), n, h.data_ptr(), counters.data_ptr())
+        ctx.synchronize()
+        return counters.view(-1, 4).to(torch.int64).sum(dim=0).cpu().numpy()
+
     # visit counts of the batch (for the algorithmic byte count), outside the timed region
-    counters = torch.zeros(n_rays * 4, dtype=torch.int32, device=dev)
-    ctx.trace_closest_counted(rays.data_ptr(), n_rays, hits.data_ptr(), counters.data_ptr())
-    ctx.synchronize()
-    csum = counters.view(-1, 4).to(torch.int64).sum(dim=0).cpu().numpy()
-    del counters
-    bytes_per_launch = algorithmic_bytes(n_rays, int(csum[0]), int(csum[1]), int(csum[2]))
+    csum = visit_sums(rays, n_rays)
+    bytes_per_launch = ray_bytes(n_rays, int(csum[0]), int(csum[1]), int(csum[2]), 16.0)
 
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- leg 1: closest-hit Mrays/s
-    for _ in range(args.warmup):
-        ctx.trace_closest(rays.data_ptr(), n_rays, hits.data_ptr())
-    ctx.synchronize()
-    ctx.reset_stats()
-    ctx.set_profiling(True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ctx.trace_closest(rays.data_ptr(), n_rays, hits.data_ptr())
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ctx.set_profiling(False)
-    st = ctx.stats()
-    kernel_ms = st.ms_closest / max(1, st.n_closest)
-    elapsed = pt.sharding.max_over_ranks(elapsed, dev)
-    if distributed:
-        nr = torch.tensor([n_rays], dtype=torch.int64, device=dev)
-        dist.all_reduce(nr, op=dist.ReduceOp.SUM)
-        total_rays = int(nr.item())
-    else:
-        total_rays = n_rays
+    def total_over_ranks(x):
+        if not distributed:
+            return x
+        t = torch.tensor([x], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(t.item())
+
+    # ---- leg 1: closest-hit Mrays/s, trace mode 0 (the value) and trace mode 2
+    def closest_leg(mode):
+        ctx.set_trace_mode(mode)
+        for _ in range(args.warmup):
+            ctx.trace_closest(rays.data_ptr(), n_rays, hits.data_ptr())
+        ctx.synchronize()
+        ctx.reset_stats()
+        ctx.set_profiling(True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.trace_closest(rays.data_ptr(), n_rays, hits.data_ptr())
+        barrier()
+        dt = time.perf_counter() - t0
+        ctx.set_profiling(False)
+        st = ctx.stats()
+        ctx.set_trace_mode(0)
+        return pt.sharding.max_over_ranks(dt, dev), st.ms_closest / max(1, st.n_closest), int(st.n_closest)
+
+    total_rays = total_over_ranks(n_rays)
+    wide_elapsed, wide_kernel_ms, _ = closest_leg(2)
+    hits_wide = hits.clone()
+    elapsed, kernel_ms, launches = closest_leg(0)
     mrays = total_rays * args.steps / elapsed / 1e6
+    a, b = hits.view(torch.int32).view(-1, 8), hits_wide.view(torch.int32).view(-1, 8)
+    ids_differ = int(((a[:, 3] != b[:, 3]) | (a[:, 4] != b[:, 4])).sum().item())
+    t_differ_same_id = int((((a[:, 3] == b[:, 3]) & (a[:, 4] == b[:, 4])) & (a[:, 0] != b[:, 0])).sum().item())
+    del hits_wide
+    modes = {"0": {"mrays_per_s": mrays, "kernel_ms": kernel_ms, "parity": "reference-exact (ids, t, u, v bit-equal to the oracle in the GPU tests)"},
+             "2": {"mrays_per_s": total_rays * args.steps / wide_elapsed / 1e6, "kernel_ms": wide_kernel_ms,
+                   "ids_differing_from_mode_0": ids_differ, "ids_differing_frac": ids_differ / n_rays,
+                   "t_bits_differing_where_ids_agree": t_differ_same_id, "parity": "meets the bar when ids_differing_frac <= 1e-5"}}
 
     # ---- leg 2: spp/s of the full path tracer, iterations strided over ranks + film reduce
     spp = None
@@ -143,68 +187,145 @@ def main():
         for w_pass in range(4):  # untimed: consecutive passes rotate through the library's sets of path state (allocated on first use)
             ctx.render_batch(W, H, w_pass * B, B)
         ctx.synchronize()
+
+        def render_leg(mode, reduce):
+            ctx.set_trace_mode(mode)
+            ctx.integrator_reset(W, H)
+            ctx.reset_stats()
+            barrier()
+            t0 = time.perf_counter()
+            # rank r owns the iteration blocks r, r+N, r+2N, ... of B consecutive iterations each
+            for first, count in pt.sharding.iteration_blocks(rank, world, args.spp_steps * world, B):
+                ctx.render_batch(W, H, first, count)
+            ctx.synchronize()
+            if reduce:
+                ctx.film_copy_to_device(film.data_ptr())
+                pt.sharding.reduce_film(film, dst=0)
+            barrier()
+            dt = pt.sharding.max_over_ranks(time.perf_counter() - t0, dev)
+            ctx.set_trace_mode(0)
+            return dt
+
+        spp_elapsed = render_leg(0, True)
+        st2 = ctx.stats()
+        # the other trace modes, reported beside the reference-exact figure, never as `value`
+        other = {str(m): args.spp_steps * world / render_leg(m, False) for m in (1, 2, 3)}
+        spp_rate = args.spp_steps * world / spp_elapsed
+
+        # Algorithmic bytes of one sample per pixel (iteration 0 of this scene): per bounce the extension
+        # and shadow rays are captured and their visits counted in the reference's binary BVH.
+        cap = W * H
+        tmp = torch.empty(cap * 8, dtype=torch.float32, device=dev)
+        ext_bytes = sh_bytes = state_bytes = 0.0
+        n_ext = n_sh = 0
+        for bounce in range(depth):
+            n = ctx.capture_bounce_rays(W, H, 0, bounce, tmp.data_ptr(), cap)
+            if n == 0:
+                break
+            c = visit_sums(tmp, n)
+            ext_bytes += ray_bytes(n, int(c[0]), int(c[1]), int(c[2]), 16.0)
+            state_bytes += 2.0 * STATE_BYTES * n
+            n_ext += n
+            m = ctx.capture_shadow_rays(W, H, 0, bounce, tmp.data_ptr(), cap)
+            if m:
+                c = visit_sums(tmp, m, any_hit=True)
+                sh_bytes += ray_bytes(m, int(c[0]), int(c[1]), int(c[2]), 4.0)
+                n_sh += m
+        del tmp
+        P = float(W * H)
+        sample_bytes = 88.0 * P + ext_bytes + sh_bytes + state_bytes + 24.0 * P
+        ext_streamed, sh_streamed = 48.0 * n_ext, 36.0 * n_sh  # ray in + hit / flag out
+        streamed_bytes = 88.0 * P + ext_streamed + sh_streamed + state_bytes + 24.0 * P
+        # kernel times of one pass, passes one after the other on one stream (HIP events around every launch)
         ctx.integrator_reset(W, H)
         ctx.reset_stats()
-        barrier()
-        t0 = time.perf_counter()
-        # rank r owns the iteration blocks r, r+N, r+2N, ... of B consecutive iterations each
-        for first, count in pt.sharding.iteration_blocks(rank, world, args.spp_steps * world, B):
-            ctx.render_batch(W, H, first, count)
+        ctx.set_profiling(True)
+        ctx.render_batch(W, H, 0, B)
         ctx.synchronize()
-        ctx.film_copy_to_device(film.data_ptr())
-        pt.sharding.reduce_film(film, dst=0)
-        barrier()
-        spp_elapsed = pt.sharding.max_over_ranks(time.perf_counter() - t0, dev)
-        st2 = ctx.stats()
-        # the same leg with trace mode 1 (any-hit searches skip boxes beyond the shadow ray's t_max, which
-        # the reference does not do): reported beside the reference-exact figure, never as `value`
-        ctx.set_trace_mode(1)
-        ctx.integrator_reset(W, H)
-        barrier()
-        t0 = time.perf_counter()
-        for first, count in pt.sharding.iteration_blocks(rank, world, args.spp_steps * world, B):
-            ctx.render_batch(W, H, first, count)
-        ctx.synchronize()
-        barrier()
-        mode1_elapsed = pt.sharding.max_over_ranks(time.perf_counter() - t0, dev)
-        ctx.set_trace_mode(0)
-        spp = {"spp_per_s": args.spp_steps * world / spp_elapsed, "ms_per_spp": spp_elapsed * 1e3 / (args.spp_steps * world),
-               "mpaths_per_s": args.spp_steps * world * W * H / spp_elapsed / 1e6,
+        ctx.set_profiling(False)
+        stp = ctx.stats()
+        per_gpu_rate = spp_rate / world
+        spp = {"spp_per_s": spp_rate, "ms_per_spp": spp_elapsed * 1e3 / (args.spp_steps * world),
+               "mpaths_per_s": spp_rate * W * H / 1e6,
                "rays_last_pass": {"closest": int(st2.closest_rays), "shadow": int(st2.shadow_rays)},
                "iterations": args.spp_steps * world, "samples_in_flight": B,
-               "spp_per_s_trace_mode_1": args.spp_steps * world / mode1_elapsed, "film_reduce": "rccl reduce(sum) to rank 0" if distributed else "none"}
+               "spp_per_s_by_trace_mode": {"0": spp_rate, **other},
+               "film_reduce": "rccl reduce(sum) to rank 0" if distributed else "none",
+               "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                            "A_sample_bytes_per_pixel": sample_bytes / P, "A_sample_streamed_bytes_per_pixel": streamed_bytes / P,
+                            "rays_per_pixel": {"closest": n_ext / P, "shadow": n_sh / P},
+                            "achieved": streamed_bytes * per_gpu_rate / 1e9, "frac": streamed_bytes * per_gpu_rate / 1e9 / HBM_PEAK_GBS,
+                            "scene_gather_achieved": (sample_bytes - streamed_bytes) * per_gpu_rate / 1e9, "scene_gather_ceiling": GATHER_CEILING_GBS,
+                            "scene_gather_frac": (sample_bytes - streamed_bytes) * per_gpu_rate / 1e9 / GATHER_CEILING_GBS,
+                            "kernels_one_pass_serial": {
+                                "k_extend": split_line(stp.ms_closest, ext_streamed * B, (ext_bytes - ext_streamed) * B),
+                                "k_shade": split_line(stp.ms_shade, state_bytes * B, 0.0),
+                                "k_shadow": split_line(stp.ms_any, sh_streamed * B, (sh_bytes - sh_streamed) * B),
+                                "k_generate": split_line(stp.ms_generate, 88.0 * P * B, 0.0),
+                                "k_film": split_line(stp.ms_film, (16.0 * B + 24.0) * P, 0.0)},
+                            "note": "per pixel and sample: 88 B generate + per extension ray A_ray + per shadow ray A_ray(any, 4 B out) + 2 x 184 B of path state "
+                                    "per bounce + 24 B film, visits counted in the reference's binary BVH on iteration 0.  `achieved` / `frac` take the bytes that "
+                                    "have to stream through HBM (rays, hit records, path state, film); the node / triangle / instance bytes are L2 / MALL "
+                                    "resident and are held against the measured dependent-gather ceiling instead.  Kernel lines: one pass of "
+                                    f"{B} samples with its launches serialised on one stream"}}
 
     # ---- leg 3: CPU baseline (rank 0, N == 1 only): the oracle's traversal on a bounded sample
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        # the oracle compiled for this machine's CPU (-O3 -march=native, multiply-adds still unfused);
+        # falls back to the portable build that ships in-tree
+        native = os.path.join(tempfile.mkdtemp(prefix="ptamd_oracle_"), "liboracle_native.so")
+        built = subprocess.call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "native", "NATIVE_OUT=" + native],
+                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 0 and os.path.exists(native)
+        if built:
+            os.environ["ORACLE_LIB"] = native
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as ora
 
         desc = hs.desc()
-        threads = max(1, min(os.cpu_count() or 1, 16))
+        # every core this process may use: the affinity mask, and the box's per-job share when it names one
+        visible = os.cpu_count() or 1
+        share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else visible
+        for var in ("OMP_NUM_THREADS", "MAX_JOBS"):
+            if os.environ.get(var, "").isdigit():
+                share = min(share, int(os.environ[var]))
+        threads = max(1, share)
         rays_h = rays[: min(n_rays, 1 << 22) * 8].cpu().numpy().view(pt.abi.RAY).reshape(-1)
         probe = rays_h[: min(len(rays_h), 100000)]
         t0 = time.perf_counter()
-        ora.trace_closest(desc, probe, nthreads=threads)
+        ref_hits = ora.trace_closest(desc, probe, nthreads=threads)
         rate = len(probe) / max(time.perf_counter() - t0, 1e-6)
-        sample = rays_h[: int(min(len(rays_h), max(len(probe), rate * args.cpu_seconds)))]
-        repeats = int(max(1, min(64, round(rate * args.cpu_seconds / len(sample)))))
+        gpu_probe = hits[: len(probe) * 8].cpu().numpy().view(pt.abi.HIT).reshape(-1)
+        probe_equal = bool(np.array_equal(ref_hits["prim"], gpu_probe["prim"]) and np.array_equal(ref_hits["t"].view(np.uint32), gpu_probe["t"].view(np.uint32)))
+        budget = 0.75 * args.cpu_seconds
+        sample = rays_h[: int(min(len(rays_h), max(len(probe), rate * budget)))]
+        repeats = int(max(1, min(64, round(rate * budget / len(sample)))))
         t0 = time.perf_counter()
         for _ in range(repeats):
             ora.trace_closest(desc, sample, nthreads=threads)
         cpu_t = time.perf_counter() - t0
+        one = sample[: max(1000, int(len(sample) * repeats / cpu_t * 0.25 * args.cpu_seconds / threads))]
+        t0 = time.perf_counter()
+        ora.trace_closest(desc, one, nthreads=1)
+        one_t = time.perf_counter() - t0
         cpu = {"value": len(sample) * repeats / cpu_t / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-               "sample": f"first {len(sample)} rays of the same batch traced {repeats}x, oracle/liboracle.so ora_trace_closest, "
-                         f"{threads} threads, {cpu_t:.1f} s"}
+               "cores_visible": visible, "single_thread_mrays_per_s": len(one) / one_t / 1e6,
+               "build": "-O3 -march=native -ffp-contract=off, compiled on this machine" if built else "-O2 portable build (native compile failed)",
+               "matches_gpu_on_probe": probe_equal,
+               "sample": f"first {len(sample)} rays of the same batch traced {repeats}x, oracle ora_trace_closest, {threads} threads "
+                         f"(the job's CPU share; the machine shows {visible}), {cpu_t:.1f} s; single thread: {len(one)} rays, {one_t:.1f} s"}
 
-    # HBM-side bytes per launch from the committed PMC passes (counters cannot be read in-process);
-    # only quoted when the profile was taken on this same batch
+    # Counters cannot be read in-process: the memory-side bytes per launch and the shader-engine counters
+    # come from the committed rocprofv3 passes of this same command (tools/profile.sh, tools/profile_sq.sh),
+    # and are only quoted when they were taken on this same batch.
     traffic = None
+    binding = None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             rec = json.load(f)["k_trace_closest"]
         if abs(rec["rays"] - n_rays) <= 0.01 * n_rays and args.rays == "captured":
             traffic = rec["traffic_bytes"]
+            binding = rec.get("binding")
     except (OSError, KeyError, ValueError):
         traffic = None
 
@@ -214,12 +335,18 @@ def main():
             "metric": f"Mrays/s incoherent closest-hit ({args.scene}, {W}x{H} {args.rays} bounce rays)", "value": mrays, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "rays_per_rank": n_rays, "scene": args.scene, "resolution": [W, H], "max_depth": depth,
+            "config": {"workload": workload, "rays_per_rank": n_rays, "scene": args.scene, "resolution": [W, H], "max_depth": depth, "trace_mode": 0,
                        "parallelism": f"rays sharded over {world} rank(s), scene replicated"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_trace_closest", "kernel_ms": kernel_ms, "launches": int(st.n_closest),
+            "roofline": {"bound": "hbm", "nominal": True, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "k_trace_closest", "kernel_ms": kernel_ms, "launches": launches,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "visits_per_ray": {"interior": csum[0] / n_rays, "tlas_leaves": csum[1] / n_rays, "triangles": csum[2] / n_rays}},
+                         "visits_per_ray": {"interior": csum[0] / n_rays, "tlas_leaves": csum[1] / n_rays, "triangles": csum[2] / n_rays},
+                         "hbm_streamed": split_line(kernel_ms, 48.0 * n_rays, bytes_per_launch - 48.0 * n_rays),
+                         "binding": binding,
+                         "note": "`achieved` / `frac` are nominal: all algorithmic bytes over the kernel time against the HBM peak.  The scene is L2 / MALL resident "
+                                 "(traffic << algorithmic bytes): hbm_streamed holds the ray / hit bytes against HBM and the node / triangle bytes against the "
+                                 "measured gather ceiling; `binding` (rocprofv3 counters of this command, profiles/) names what limits the kernel"},
+            "trace_modes": modes,
             "cpu_baseline": cpu,
             "spp": spp,
         }

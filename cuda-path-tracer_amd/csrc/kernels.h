@@ -138,9 +138,11 @@ __global__ __launch_bounds__(64) void k_trace_closest(DScene S, const pt_ray *ra
     flush_events(stats, ev);
 }
 
+template <bool COUNT>
 struct AnyIO {
     const pt_ray *rays;
     uint8_t *occluded;
+    TraceCounters *counters;
     PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax, uint32_t &) const {
         const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
         const float4 ro = rp[0], rd = rp[1];
@@ -150,20 +152,23 @@ struct AnyIO {
         return true;
     }
     template <class TR>
-    PTD void done(uint32_t i, uint32_t, const TR &, bool hit) const { occluded[i] = hit ? 1 : 0; }
+    PTD void done(uint32_t i, uint32_t, const TR &tr, bool hit) const {
+        occluded[i] = hit ? 1 : 0;
+        if (COUNT) counters[i] = tr.ctr;
+    }
     PTD bool has_pending() const { return false; }
     PTD void flush() const {}
     PTD void finish() const {}
 };
 
-template <bool WIDE = false>
+template <bool WIDE = false, bool COUNT = false>
 __global__ __launch_bounds__(64) void k_trace_any(DScene S, const pt_ray *rays, uint32_t n, uint8_t *occluded, uint32_t *cursors, uint32_t cursor_count,
-                                                  uint2 *spill, uint32_t spill_stride, DevStats *stats) {
+                                                  uint2 *spill, uint32_t spill_stride, DevStats *stats, TraceCounters *counters) {
     LaneEvents ev;
-    AnyIO io{rays, occluded};
+    AnyIO<COUNT> io{rays, occluded, counters};
     __shared__ unsigned long long lds[kWaveLdsEntries];
     const auto stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
-    trace_stream<MODE_ANY, false, WIDE>(S, io, n, make_feed(cursors, cursor_count, n), stk, ev);
+    trace_stream<MODE_ANY, COUNT, WIDE>(S, io, n, make_feed(cursors, cursor_count, n), stk, ev);
     flush_events(stats, ev);
 }
 

@@ -1383,24 +1383,36 @@ int pt_trace_closest_static(pt_ctx *ctx, const pt_ray *rays, size_t n, pt_hit *h
     return PT_OK;
 }
 
-int pt_trace_any(pt_ctx *ctx, const pt_ray *rays, size_t n, uint8_t *occluded) {
+static int TraceAny(pt_ctx *ctx, const pt_ray *rays, size_t n, uint8_t *occluded, uint32_t *counters4) {
     int st = CheckQuery(ctx, rays, occluded, n);
     if (st != PT_OK || n == 0) return st;
     DeviceGuard guard(ctx->device);
     HIP_TRY(ctx, Join(ctx));  // lane 0's spill area is shared with render passes
     HIP_TRY(ctx, hipMemsetAsync(ctx->cursor, 0, size_t(ctx->query_cursors) * kCursorStride * sizeof(uint32_t), ctx->stream));
     const uint32_t blocks = uint32_t(std::min<size_t>(ctx->grid_blocks, (n + kWave - 1) / kWave));
+    TraceCounters *ctr = reinterpret_cast<TraceCounters *>(counters4);
+    const bool wide = (ctx->trace_mode & 2) != 0;
+#define PT_LAUNCH_ANY(W, C)                                                                                                                     \
+    hipLaunchKernelGGL((k_trace_any<W, C>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), occluded, ctx->cursor, \
+                       ctx->query_cursors, ctx->lane[0].spill, ctx->spill_stride, ctx->dev_stats, ctr)
     {
         ScopedEvent ev(ctx, EV_ANY);
-        if (ctx->trace_mode & 2)
-            hipLaunchKernelGGL(k_trace_any<true>, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), occluded, ctx->cursor, ctx->query_cursors, ctx->lane[0].spill,
-                               ctx->spill_stride, ctx->dev_stats);
-        else
-            hipLaunchKernelGGL(k_trace_any<false>, dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), occluded, ctx->cursor, ctx->query_cursors, ctx->lane[0].spill,
-                               ctx->spill_stride, ctx->dev_stats);
+        if (wide && ctr) PT_LAUNCH_ANY(true, true);
+        else if (wide) PT_LAUNCH_ANY(true, false);
+        else if (ctr) PT_LAUNCH_ANY(false, true);
+        else PT_LAUNCH_ANY(false, false);
     }
+#undef PT_LAUNCH_ANY
     HIP_TRY(ctx, hipGetLastError());
     return PT_OK;
+}
+
+int pt_trace_any(pt_ctx *ctx, const pt_ray *rays, size_t n, uint8_t *occluded) { return TraceAny(ctx, rays, n, occluded, nullptr); }
+
+// Visit counters of an any-hit query, as pt_trace_closest_counted has them for closest hits.
+int pt_trace_any_counted(pt_ctx *ctx, const pt_ray *rays, size_t n, uint8_t *occluded, uint32_t *counters4) {
+    if (ctx && !counters4) return Fail(ctx, PT_ERR_INVALID, "null counter buffer");
+    return TraceAny(ctx, rays, n, occluded, counters4);
 }
 
 int pt_resolve_hits(pt_ctx *ctx, const pt_ray *rays, const pt_hit *hits, size_t n, pt_intersection *out) {

@@ -446,6 +446,9 @@ class Context:
     def trace_closest_counted(self, rays_ptr: int, n: int, hits_ptr: int, counters_ptr: int):
         self._check(self._lib.pt_trace_closest_counted(self._h, C.c_void_p(rays_ptr), n, C.c_void_p(hits_ptr), C.c_void_p(counters_ptr)))
 
+    def trace_any_counted(self, rays_ptr: int, n: int, occluded_ptr: int, counters_ptr: int):
+        self._check(self._lib.pt_trace_any_counted(self._h, C.c_void_p(rays_ptr), n, C.c_void_p(occluded_ptr), C.c_void_p(counters_ptr)))
+
     def resolve_hits(self, rays_ptr: int, hits_ptr: int, n: int, out_ptr: int):
         self._check(self._lib.pt_resolve_hits(self._h, C.c_void_p(rays_ptr), C.c_void_p(hits_ptr), n, C.c_void_p(out_ptr)))
 

@@ -403,6 +403,9 @@ int pt_resolve_hits(pt_ctx *ctx, const pt_ray *rays_device, const pt_hit *hits_d
  * callback hook (kernel/intersection.h:24-31,61,181) as a query. counters4 = n * 4 uint32. */
 int pt_trace_closest_counted(pt_ctx *ctx, const pt_ray *rays_device, size_t n, pt_hit *hits_device,
                              uint32_t *counters4_device);
+/* The same four counters for an any-hit query (the search stops at the first occluder found). */
+int pt_trace_any_counted(pt_ctx *ctx, const pt_ray *rays_device, size_t n, uint8_t *occluded_device,
+                         uint32_t *counters4_device);
 /* pt_trace_closest for callers that cannot allocate (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc): no counterpart in the reference.  The call allocates
  * nothing and creates no events: its scratch (work-feed cursors, event counters, traversal-stack

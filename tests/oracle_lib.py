@@ -33,7 +33,7 @@ def lib() -> C.CDLL:
         return _lib
     if not os.path.exists(LIB_PATH):
         build()
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(os.environ.get("ORACLE_LIB", LIB_PATH))  # bench.py's CPU-baseline leg names a build for the local CPU
     vp, i32, u32, u64, f32, sz = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_float, C.c_size_t
     fp, up = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
     dp = C.POINTER(abi.SceneDesc)

@@ -5,7 +5,7 @@ import csv
 import glob
 import sys
 
-kernel = sys.argv[1] if len(sys.argv) > 1 else "k_trace_closest<false>"
+kernel = sys.argv[1] if len(sys.argv) > 1 else "k_trace_closest<false, false>"
 base = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/sq"
 vals = {}
 for name in "abc":
@@ -26,4 +26,6 @@ for k, v in vals.items():
 if "SQ_THREAD_CYCLES_VALU" in vals and "SQ_ACTIVE_INST_VALU" in vals:
     print("lane utilisation of VALU instructions: %.3f" % (vals["SQ_THREAD_CYCLES_VALU"] / (64 * vals["SQ_ACTIVE_INST_VALU"])))
 if "SQ_INSTS_VALU" in vals and "SQ_BUSY_CYCLES" in vals:
-    print("VALU issue share of SIMD time (4 cycles per instruction, 1024 SIMDs, 32 SEs): %.3f" % (vals["SQ_INSTS_VALU"] * 4 / 1024 / (vals["SQ_BUSY_CYCLES"] / 32)))
+    print("VALU instructions x 4 cycles over SIMD time (1024 SIMDs, 32 SEs): %.3f" % (vals["SQ_INSTS_VALU"] * 4 / 1024 / (vals["SQ_BUSY_CYCLES"] / 32)))
+if "SQ_ACTIVE_INST_VALU" in vals and "SQ_BUSY_CYCLES" in vals:
+    print("VALU pipe busy (SQ_ACTIVE_INST_VALU quad-cycles x 4 over SIMD time): %.3f" % (vals["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (vals["SQ_BUSY_CYCLES"] / 32)))

@@ -2,7 +2,8 @@
 """Condenses gpurun_out/prof (written by tools/profile.sh) into the files kept under profiles/:
   <tag>_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the default bench command
   <tag>_pmc_per_kernel.csv       mean counter value per dispatch, per kernel, of every --pmc pass
-  traffic.json                   memory-side bytes per k_trace_closest launch (read by bench.py)
+  traffic.json                   memory-side bytes per k_trace_closest launch and, when tools/profile_sq.sh has run,
+                                 the shader-engine counters that name what limits it (read by bench.py)
 Usage: python tools/summarize_profile.py <tag>"""
 import csv
 import glob
@@ -23,8 +24,49 @@ def newest(pattern):
 
 
 def short(name):
-    n = name.split("(")[0].replace("void ", "").replace("ptd::", "")
-    return n.split("<")[0] + ("<true>" if "<true>" in n else "")
+    """Kernel name with its template arguments: k_trace_closest<false, false> is the reference-exact
+    query, <false, true> the 4-wide one, <true, ...> the counting variants."""
+    return name.split("(")[0].replace("void ", "").replace("ptd::", "").strip()
+
+
+EXACT = "k_trace_closest<false, false>"
+
+
+def sq_binding(base):
+    """What limits the closest-hit kernel, from the shader-engine counter passes of tools/profile_sq.sh."""
+    vals = {}
+    for name in "abc":
+        fs = glob.glob(os.path.join(base, name, "*", "*counter_collection.csv"))
+        if not fs:
+            continue
+        acc = defaultdict(list)
+        for r in csv.DictReader(open(fs[0])):
+            if short(r["Kernel_Name"]) != EXACT:
+                continue
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            vals["vgpr_count_field"] = r.get("VGPR_Count")
+            vals["lds_bytes_per_workgroup"] = r.get("LDS_Block_Size")
+        for k, v in acc.items():
+            vals[k] = sum(v) / len(v)
+    if "SQ_ACTIVE_INST_VALU" not in vals or "SQ_BUSY_CYCLES" not in vals:
+        return None
+    simds, ses = 1024.0, 32.0
+    kernel_cycles = vals["SQ_BUSY_CYCLES"] / ses  # SQ_BUSY_CYCLES is summed over the 32 shader engines
+    out = {"counters": {k: v for k, v in vals.items() if isinstance(v, float)},
+           "kernel_cycles": kernel_cycles,
+           # SQ_ACTIVE_INST_VALU counts quad-cycles in which a SIMD executes a vector instruction: a direct
+           # measure of VALU pipe occupancy that assumes no cycles-per-instruction figure
+           "valu_busy_frac": vals["SQ_ACTIVE_INST_VALU"] * 4.0 / (simds * kernel_cycles),
+           "valu_quad_cycles_per_instruction": vals["SQ_ACTIVE_INST_VALU"] / vals["SQ_INSTS_VALU"] if vals.get("SQ_INSTS_VALU") else None,
+           "lane_utilisation": vals["SQ_THREAD_CYCLES_VALU"] / (64.0 * vals["SQ_ACTIVE_INST_VALU"]) if vals.get("SQ_THREAD_CYCLES_VALU") else None,
+           "wave_cycles_waiting_frac": vals["SQ_WAIT_ANY"] / vals["SQ_WAVE_CYCLES"] if vals.get("SQ_WAIT_ANY") and vals.get("SQ_WAVE_CYCLES") else None}
+    if vals.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+        out["tcp_accesses_per_cycle_per_cu"] = vals["TCP_TOTAL_CACHE_ACCESSES_sum"] / (256.0 * kernel_cycles)
+        out["l1_hit_frac"] = 1.0 - vals.get("TCP_TCC_READ_REQ_sum", 0.0) / vals["TCP_TOTAL_CACHE_ACCESSES_sum"]
+    out["resource"] = ("VALU issue: the vector pipes are busy for valu_busy_frac of the launch at lane_utilisation of their lanes, "
+                       "4 waves per SIMD (116 VGPRs, 10 KB of LDS per wave); HBM carries a few per cent of the algorithmic bytes")
+    out["source"] = "tools/profile_sq.sh: rocprofv3 --pmc, three separate passes over bench.py --steps 3 --spp-steps 0"
+    return out
 
 
 def main():
@@ -51,8 +93,8 @@ def main():
     line = [ln for ln in open(os.path.join(PROF, "bench_fetch.log")) if ln.startswith("{")][-1]
     bench = json.loads(line)
     rays = bench["config"]["rays_per_rank"]
-    fetch_kb = means[("fetch", "k_trace_closest", "FETCH_SIZE")]
-    write_kb = means[("write", "k_trace_closest", "WRITE_SIZE")]
+    fetch_kb = means[("fetch", EXACT, "FETCH_SIZE")]
+    write_kb = means[("write", EXACT, "WRITE_SIZE")]
     s32, g64 = means[("calib_fetch", "stream32", "FETCH_SIZE")], means[("calib_fetch", "gather64", "FETCH_SIZE")]
     w32 = means[("calib_write", "stream32", "WRITE_SIZE")]
     traffic = fetch_kb * 1024 + rays * 32 * 0.5 + write_kb * 1024
@@ -62,11 +104,14 @@ def main():
                       f"records exactly (gather64: {g64:.0f} KB for 1073.7 MB); the 32-byte ray stream (rays*32 B) is therefore added once more "
                       f"at half weight; WRITE_SIZE is exact for 32-byte records ({w32:.0f} KB for 536.9 MB)",
         "traffic_bytes": traffic,
+        "l2_hit_frac": (means[("l2", EXACT, "TCC_HIT_sum")] / (means[("l2", EXACT, "TCC_HIT_sum")] + means[("l2", EXACT, "TCC_MISS_sum")])
+                        if ("l2", EXACT, "TCC_HIT_sum") in means else None),
+        "binding": sq_binding(os.path.join(ROOT, "gpurun_out", "sq")),
         "source": f"profiles/{tag}_pmc_per_kernel.csv (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of bench.py --steps 3)"}},
         open(os.path.join(OUT, "traffic.json"), "w"), indent=1)
     print("traffic bytes per launch", traffic)
     for r in rows:
-        if r[1].startswith("k_trace_closest") and "<true>" not in r[1]:
+        if r[1] == EXACT:
             print(r)
 
 
