@@ -190,17 +190,12 @@ def main():
 
         def render_leg(mode, reduce):
             ctx.set_trace_mode(mode)
-            ctx.integrator_reset(W, H)
             ctx.reset_stats()
             barrier()
             t0 = time.perf_counter()
-            # rank r owns the iteration blocks r, r+N, r+2N, ... of B consecutive iterations each
-            for first, count in pt.sharding.iteration_blocks(rank, world, args.spp_steps * world, B):
-                ctx.render_batch(W, H, first, count)
-            ctx.synchronize()
-            if reduce:
-                ctx.film_copy_to_device(film.data_ptr())
-                pt.sharding.reduce_film(film, dst=0)
+            # rank r owns the iteration blocks r, r+N, r+2N, ... of B consecutive iterations each; the job ends
+            # with the films summed onto rank 0 (sharding.render_job)
+            pt.sharding.render_job(ctx, W, H, args.spp_steps * world, B, rank, world, film if reduce else None)
             barrier()
             dt = pt.sharding.max_over_ranks(time.perf_counter() - t0, dev)
             ctx.set_trace_mode(0)

@@ -1,6 +1,7 @@
 // libptamd.so: implementation of include/ptamd.h for gfx950 (MI355X).
 // Context and device memory management, scene validation and re-packing, kernel launches.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -1290,6 +1291,101 @@ int pt_film_upload(pt_ctx *ctx, const float *rgb_host) {
     HIP_TRY(ctx, Join(ctx));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->film, rgb_host, size_t(ctx->width) * ctx->height * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, SyncAll(ctx));
+    return PT_OK;
+}
+
+// ------------------------------------------------------------------ multi-GPU film reduce (RCCL)
+// RCCL is bound at run time, the first time one of these entry points is called: a process that
+// never reduces a film (one GPU) needs no librccl, and a process that already holds a copy (PyTorch
+// brings its own) keeps using that one instead of loading a second.
+namespace {
+struct RcclId {
+    char internal[128];  // ncclUniqueId
+};
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(RcclId *) = nullptr;
+    int (*CommInitRank)(void **, int, RcclId, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*Reduce)(const void *, void *, size_t, int, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string error;
+};
+std::mutex g_rccl_mutex;
+RcclApi g_rccl;
+
+const RcclApi *Rccl() {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.lib) return &g_rccl;
+    static const char *const kNames[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    void *lib = nullptr;
+    for (const char *n : kNames)
+        if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;  // a copy the process already holds
+    for (size_t k = 0; !lib && k < sizeof(kNames) / sizeof(kNames[0]); ++k) lib = dlopen(kNames[k], RTLD_NOW | RTLD_LOCAL);
+    if (!lib) {
+        g_rccl.error = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "not found");
+        return nullptr;
+    }
+    RcclApi api;
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    api.Reduce = reinterpret_cast<decltype(api.Reduce)>(dlsym(lib, "ncclReduce"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.Reduce || !api.GetErrorString) {
+        g_rccl.error = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclReduce / ncclGetErrorString";
+        dlclose(lib);
+        return nullptr;
+    }
+    api.lib = lib;
+    g_rccl = api;
+    return &g_rccl;
+}
+constexpr int kNcclFloat = 7, kNcclSum = 0;  // ncclFloat32, ncclSum (rccl.h)
+}  // namespace
+
+int pt_rccl_unique_id(pt_ctx *ctx, void *id128) {
+    if (!id128) return Fail(ctx, PT_ERR_INVALID, "pt_rccl_unique_id: null buffer");
+    const RcclApi *r = Rccl();
+    if (!r) return Fail(ctx, PT_ERR_DEVICE, "%s", g_rccl.error.c_str());
+    const int rc = r->GetUniqueId(static_cast<RcclId *>(id128));
+    if (rc != 0) return Fail(ctx, PT_ERR_DEVICE, "ncclGetUniqueId: %s", r->GetErrorString(rc));
+    return PT_OK;
+}
+
+int pt_rccl_comm_create(pt_ctx *ctx, int nranks, const void *id128, int rank, void **comm_out) {
+    if (!ctx || !id128 || !comm_out) return Fail(ctx, PT_ERR_INVALID, "pt_rccl_comm_create: null argument");
+    *comm_out = nullptr;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return Fail(ctx, PT_ERR_INVALID, "pt_rccl_comm_create: rank %d outside %d ranks", rank, nranks);
+    const RcclApi *r = Rccl();
+    if (!r) return Fail(ctx, PT_ERR_DEVICE, "%s", g_rccl.error.c_str());
+    DeviceGuard guard(ctx->device);  // the communicator belongs to the context's GPU
+    RcclId id;
+    std::memcpy(&id, id128, sizeof(id));
+    const int rc = r->CommInitRank(comm_out, nranks, id, rank);
+    if (rc != 0) return Fail(ctx, PT_ERR_DEVICE, "ncclCommInitRank: %s", r->GetErrorString(rc));
+    return PT_OK;
+}
+
+int pt_rccl_comm_destroy(pt_ctx *ctx, void *comm) {
+    if (!comm) return PT_OK;
+    const RcclApi *r = Rccl();
+    if (!r) return Fail(ctx, PT_ERR_DEVICE, "%s", g_rccl.error.c_str());
+    const int rc = r->CommDestroy(comm);
+    if (rc != 0) return Fail(ctx, PT_ERR_DEVICE, "ncclCommDestroy: %s", r->GetErrorString(rc));
+    return PT_OK;
+}
+
+// film(root) = sum over ranks of film(rank), in place, on the context's stream after the passes in flight.
+int pt_film_reduce(pt_ctx *ctx, void *comm, int root) {
+    if (!ctx || !comm) return Fail(ctx, PT_ERR_INVALID, "pt_film_reduce: null argument");
+    if (!ctx->integrator_ready) return Fail(ctx, PT_ERR_STATE, "no film: integrator not initialised");
+    const RcclApi *r = Rccl();
+    if (!r) return Fail(ctx, PT_ERR_DEVICE, "%s", g_rccl.error.c_str());
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, Join(ctx));
+    const int rc = r->Reduce(ctx->film, ctx->film, size_t(ctx->width) * ctx->height * 3, kNcclFloat, kNcclSum, root, comm, ctx->stream);
+    if (rc != 0) return Fail(ctx, PT_ERR_DEVICE, "ncclReduce: %s", r->GetErrorString(rc));
     return PT_OK;
 }
 

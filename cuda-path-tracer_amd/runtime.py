@@ -399,6 +399,24 @@ class Context:
         f = np.ascontiguousarray(film, np.float32)
         self._check(self._lib.pt_film_upload(self._h, abi.vptr(f)))
 
+    # multi-GPU film reduce over RCCL (one process per GPU)
+    def rccl_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        self._check(self._lib.pt_rccl_unique_id(self._h, buf))
+        return buf.raw
+
+    def rccl_comm_create(self, nranks: int, unique_id: bytes, rank: int) -> int:
+        comm = C.c_void_p()
+        self._check(self._lib.pt_rccl_comm_create(self._h, nranks, C.create_string_buffer(unique_id, 128), rank, C.byref(comm)))
+        return comm.value
+
+    def rccl_comm_destroy(self, comm: int):
+        self._check(self._lib.pt_rccl_comm_destroy(self._h, C.c_void_p(comm)))
+
+    def film_reduce(self, comm: int, root: int = 0):
+        """film(root) = sum of the ranks' films (ncclReduce on the context's stream, asynchronous)."""
+        self._check(self._lib.pt_film_reduce(self._h, C.c_void_p(comm), root))
+
     def display_download(self, w, h, iterations) -> np.ndarray:
         out = np.zeros((h, w, 4), np.uint8)
         self._check(self._lib.pt_display_download(self._h, iterations, abi.vptr(out)))

@@ -40,8 +40,33 @@ def reduce_film(film, dst: int = 0):
     import torch.distributed as dist
 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
+        if film.is_cuda and dist.get_backend() == "gloo":  # CPU-only collective (tests): stage through host memory
+            host = film.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+            film.copy_(host)
+        else:
+            dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
     return film
+
+
+def render_job(ctx, width: int, height: int, total_iterations: int, block: int, rank: int, world: int, film=None):
+    """One rank's part of a sample-sharded render: clears its private film (only the rank that owns
+    iteration 0 would get that from pt_render_batch), submits its iteration blocks back to back, and,
+    given a device tensor `film` of W*H*3 fp32, ends with the one collective of the job: the private
+    films summed onto rank 0 (`film` holds the sum there, and the context's film is replaced by it).
+    Returns the number of iterations this rank rendered."""
+    ctx.integrator_reset(width, height)
+    done = 0
+    for first, count in iteration_blocks(rank, world, total_iterations, block):
+        ctx.render_batch(width, height, first, count)
+        done += count
+    ctx.synchronize()
+    if film is not None:
+        ctx.film_copy_to_device(film.data_ptr())
+        reduce_film(film, dst=0)
+        if rank == 0 and world > 1:
+            ctx.film_copy_from_device(film.data_ptr())
+    return done
 
 
 def max_over_ranks(seconds: float, device) -> float:

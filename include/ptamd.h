@@ -330,6 +330,22 @@ int pt_display_download(pt_ctx *ctx, int iterations, uint8_t *rgba_host);
 int pt_tonemap(pt_ctx *ctx, const float *film_device, int width, int height, int iterations,
                uint8_t *rgba_device);
 
+/* ------------------------------------------------------- multi-GPU film reduce */
+
+/* One process per GPU renders its share of the iterations into its own film (the film is the only
+ * shared mutable state of the reference's integrator and it is additive, path_trace.cu:391-407); the
+ * job ends with film(root) = sum of all films.  No counterpart in the reference, which runs on one GPU.
+ * pt_film_reduce issues ncclReduce(sum, fp32, W*H*3, in place) on the context's stream, ordered after
+ * the render passes in flight like every other film access; `comm` is an ncclComm_t of the caller's
+ * (RCCL), whose GPU is the context's.  librccl is bound at run time on first use, so single-GPU users
+ * need not have it.  The three helpers wrap ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy for
+ * hosts that do not link RCCL themselves; id128 is the 128-byte ncclUniqueId, created on one rank and
+ * handed to the others by the caller.                                                            */
+int pt_film_reduce(pt_ctx *ctx, void *nccl_comm, int root);
+int pt_rccl_unique_id(pt_ctx *ctx, void *id128);
+int pt_rccl_comm_create(pt_ctx *ctx, int nranks, const void *id128, int rank, void **nccl_comm_out);
+int pt_rccl_comm_destroy(pt_ctx *ctx, void *nccl_comm);
+
 /* ------------------------------------------------------- debug integrator */
 
 /* DebugVisualizeMode / BVH_VisualizeMode / IntegratorState (kernel/device_types.h:10-34;
