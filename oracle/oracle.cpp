@@ -4,12 +4,16 @@
 // relative to the reference's src/ directory).  Only tests/, the smoke check and
 // the cpu_baseline leg of bench.py may load this library; the product never does.
 //
-// parity unpinned: the reference holds no tests, golden vectors or fixtures
-// and cannot be compiled in this image (its glm dependency is absent and may not
-// be replaced by a stand-in), so nothing here was checked against reference
-// output.  What pins this file instead: analytic known answers, the brute-force
-// all-triangles search (the reference's own cross-check, IntersectSceneNaive)
-// and structural BVH invariants, all in tests/.
+// parity unpinned, except for two pieces: the reference holds no tests, golden vectors
+// or fixtures, and the code of this path cannot be compiled in this image (its glm
+// dependency is absent and may not be replaced by a stand-in), so the arithmetic here
+// was not checked against reference output.  The two exceptions are the files of the
+// reference that compile unmodified on their own: PCG_Hash (math/hash.h) and Stack
+// (utils/stack.h) below are checked against known answers produced by those headers
+// (oracle/ref_probe.cpp -> tests/golden/ref_pins.npz, tests/test_ref_pins.py).  What
+// pins the rest: analytic known answers, the brute-force all-triangles search (the
+// reference's own cross-check, IntersectSceneNaive) and structural BVH invariants,
+// all in tests/.
 //
 // Where the reference relies on hardware this target lacks (CUDA texture units),
 // the definition used here is stated at the function.
@@ -1841,6 +1845,27 @@ void ora_sample_texture3(const pt_scene_desc *desc, int texture_id, float u, flo
     rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
 }
 float ora_sample_texture1(const pt_scene_desc *desc, int texture_id, float u, float v) { return SampleTexture1(*desc, texture_id, {u, v}); }
+// Math::PCG_Hash (math/hash.h:5-9) as the oracle restates it, for the known-answer vectors of the reference's own header.
+uint32_t ora_pcg_hash(uint32_t input) { return PCG_Hash(input); }
+
+// The oracle's Stack (utils/stack.h:3-22) driven by a script: v > 0 pushes node v, 0 pops.  out receives, per
+// pop, the popped node and whether the stack is empty afterwards; returns the final top.
+uint32_t ora_stack_script(const uint32_t *script, int n, uint32_t *out) {
+    Stack s;
+    s.drops = nullptr;
+    s.maxdepth = nullptr;
+    int k = 0;
+    for (int i = 0; i < n; ++i) {
+        if (script[i] > 0) {
+            s.Push(StackItem{script[i], 0.0f});
+        } else {
+            out[k++] = s.Pop().node_index;
+            out[k++] = s.Empty() ? 1u : 0u;
+        }
+    }
+    return s.top;
+}
+
 void ora_pcg_stream(int px, int py, int iteration, int n, float *out) {
     Sampler s;
     SeedSampler(s, px, py, iteration);

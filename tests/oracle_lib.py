@@ -67,6 +67,8 @@ def lib() -> C.CDLL:
         "ora_sample_texture3": (None, [dp, i32, f32, f32, fp]),
         "ora_sample_texture1": (f32, [dp, i32, f32, f32]),
         "ora_pcg_stream": (None, [i32, i32, i32, i32, fp]),
+        "ora_pcg_hash": (u32, [u32]),
+        "ora_stack_script": (u32, [up, i32, up]),
         "ora_camera_ray": (None, [C.POINTER(abi.Camera), i32, i32, f32, f32, fp, fp]),
     }
     for name, (res, args) in sig.items():
@@ -212,6 +214,19 @@ def debug_render(desc, w, h, state, nthreads=1):
     rgba = np.zeros((h, w, 4), np.uint8)
     lib().ora_debug_render(C.byref(desc), w, h, C.byref(state), abi.vptr(image), abi.vptr(rgba), nthreads)
     return image, rgba
+
+
+def pcg_hash(values):
+    L = lib()
+    return np.array([L.ora_pcg_hash(int(v)) for v in values], np.uint32)
+
+
+def stack_script(script):
+    """Runs push (v > 0) / pop (0) operations on the oracle's 64-entry stack -> (pops [k,2], final top)."""
+    s = np.ascontiguousarray(script, np.uint32)
+    out = np.zeros(2 * int((s == 0).sum()) + 2, np.uint32)
+    top = lib().ora_stack_script(abi.uptr(s), len(s), abi.uptr(out))
+    return out[: 2 * int((s == 0).sum())].reshape(-1, 2), int(top)
 
 
 def pcg_stream(px, py, iteration, n):
