@@ -5,9 +5,11 @@ Same-seed parity: both sides draw the same PCG streams in the same order.  Trave
 bit-exact, so a pixel only differs when a transcendental (sin/cos/sqrt inside sampling, a few
 ulps between libm and the device library) flips a discrete decision: a Russian-roulette or
 lobe choice, or a triangle boundary.  Such pixels take a different but equally valid path.
-Stated tolerance: >= 97 % of the pixels of one sample agree to |d| <= 1e-4 + 1e-3*|ref|
-per channel, and the relative RMSE of a 16-sample film against the oracle's 16-sample film
-stays below 10 % of the film mean."""
+Stated tolerance, set just under what tests/parity_report.py measures (profiles/r2_parity_report.json:
+one sample 0.9994 .. 1.0 of the pixels over the eight scenes, 16 samples of the teapot 0.9990, RMSE
+0.18 % of the mean): >= 99.8 % of the pixels of one sample agree to |d| <= 1e-4 + 1e-3*|ref| per
+channel; after 16 samples >= 99.5 % agree to 1e-3 + 2e-3*|ref| and the RMSE against the oracle's
+16-sample film stays below 0.5 % of the film mean."""
 import numpy as np
 import pytest
 
@@ -34,7 +36,7 @@ def test_one_sample_matches_oracle_per_pixel(pt, ora, gpu_ctx, scene_factory, ti
     assert np.isfinite(film).all()
     assert ref.mean() > 1e-3
     close = (np.abs(film - ref) <= 1e-4 + 1e-3 * np.abs(ref)).all(axis=2)
-    assert close.mean() >= 0.97, f"{name}: only {close.mean():.4f} of the pixels agree"
+    assert close.mean() >= 0.998, f"{name}: only {close.mean():.4f} of the pixels agree"
     st = gpu_ctx.stats()
     assert st.paths == w * h and st.closest_rays >= w * h and st.nan_pixels == 0 and st.stack_drops == 0
 
@@ -60,9 +62,9 @@ def test_accumulated_film_rmse(pt, ora, gpu_ctx, scene_factory):
     hs = scene_factory("teapot", w, h, 6)
     film, ref, _ = _films(pt, ora, gpu_ctx, hs, w, h, n)
     rmse = float(np.sqrt(np.mean((film / n - ref / n) ** 2)))
-    assert rmse <= 0.10 * float(ref.mean() / n), f"RMSE {rmse} vs mean {ref.mean() / n}"
+    assert rmse <= 0.005 * float(ref.mean() / n), f"RMSE {rmse} vs mean {ref.mean() / n}"
     close = (np.abs(film - ref) <= 1e-3 + 2e-3 * np.abs(ref)).all(axis=2)
-    assert close.mean() >= 0.75  # every sample can flip a decision; most pixels never do
+    assert close.mean() >= 0.995  # every sample can flip a decision; hardly any pixel ever does
 
 
 def test_render_is_bitwise_reproducible(pt, gpu_ctx, scene_factory):
@@ -289,7 +291,7 @@ def test_light_without_geometry_samples_black(pt, ora, gpu_ctx, tiny_scene):
         ref, _ = ora.render(d, w, h, it, ref, nthreads=8)
     film = gpu_ctx.film_download(w, h)
     close = (np.abs(film - ref) <= 1e-4 + 1e-3 * np.abs(ref)).all(axis=2)
-    assert close.mean() >= 0.97 and ref.mean() > 1e-3
+    assert close.mean() >= 0.998 and ref.mean() > 1e-3
     # the extra light takes a third of the picks: the film is darker than the plain scene's
     gpu_ctx.upload(tiny_scene.desc())
     gpu_ctx.integrator_init(w, h)

@@ -7,8 +7,10 @@ triangle test on the same triangle record, so wherever the ids agree the distanc
 barycentrics are in fact bit-equal, which the tests also require).  Any-hit flags: mode 2 tests every
 box like the reference, flags equal except <= 1e-5 of the rays; mode 3 also skips boxes that start
 beyond the ray's t_max, which can only turn "occluded" into "free", for at most 2e-3 of a scene's
-shadow rays (an occluder within rounding of t_max, see pt_set_trace_mode).  Rendered film: >= 97 % of
-the pixels of one sample within |d| <= 1e-4 + 1e-3 |ref| of the oracle's film."""
+shadow rays (an occluder within rounding of t_max, see pt_set_trace_mode).  Rendered film of one
+sample within |d| <= 1e-4 + 1e-3 |ref| of the oracle's film on >= 99.8 % of the pixels in mode 2 (measured:
+the same shares as mode 0, 0.9994 .. 1.0) and >= 99.5 % in mode 3 (measured 0.9964 .. 1.0; the lost
+occluders brighten a few pixels); profiles/r2_parity_report.json."""
 import numpy as np
 import pytest
 
@@ -128,7 +130,7 @@ def test_wide_one_sample_film_matches_oracle(pt, ora, gpu_ctx, scene_factory, ti
     ref, _ = ora.render(desc, w, h, 0, nthreads=8)
     assert np.isfinite(film).all() and ref.mean() > 1e-3
     close = (np.abs(film - ref) <= 1e-4 + 1e-3 * np.abs(ref)).all(axis=2)
-    assert close.mean() >= 0.97, f"{name} mode {mode}: only {close.mean():.4f} of the pixels agree"
+    assert close.mean() >= (0.998 if mode == 2 else 0.995), f"{name} mode {mode}: only {close.mean():.4f} of the pixels agree"
     assert st.paths == w * h and st.nan_pixels == 0 and st.stack_drops == 0
 
 
