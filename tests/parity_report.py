@@ -2,7 +2,7 @@
 """Same-seed agreement of the GPU render with the CPU oracle, per scene and trace mode: share of the
 pixels that agree after 1 and after 16 samples, RMSE of the 16-sample image relative to its mean.
 The numbers the thresholds of tests/test_gpu_render.py and tests/test_gpu_wide.py are set from; the
-output of the last run is kept as profiles/<round>_parity_report.json.
+output of the last run is kept as profiles/parity_report.json.
 
     python tests/parity_report.py [out.json]
 """

@@ -5,7 +5,7 @@ against the CPU oracle, through the C ABI.  20 001 instances is near the 32 767 
 
 Bars: traversal bit-equal to the oracle (ids, distances, barycentrics, visit counts); one-sample
 film parity per pixel to |d| <= 1e-4 + 1e-3 |ref| on >= 99.5 % of the pixels (measured 0.9994 after one
-sample, profiles/r2_parity_report.json; the others took a different, equally valid path after a one-ulp
+sample, profiles/parity_report.json; the others took a different, equally valid path after a one-ulp
 transcendental difference); the 4K frame, which the
 oracle cannot render in test time, is checked through properties: bitwise repeatability, exact
 per-bounce ray counts from call to call, one path per pixel, no dropped stack pushes, no NaNs."""

@@ -5,7 +5,7 @@ Same-seed parity: both sides draw the same PCG streams in the same order.  Trave
 bit-exact, so a pixel only differs when a transcendental (sin/cos/sqrt inside sampling, a few
 ulps between libm and the device library) flips a discrete decision: a Russian-roulette or
 lobe choice, or a triangle boundary.  Such pixels take a different but equally valid path.
-Stated tolerance, set just under what tests/parity_report.py measures (profiles/r2_parity_report.json:
+Stated tolerance, set just under what tests/parity_report.py measures (profiles/parity_report.json:
 one sample 0.9994 .. 1.0 of the pixels over the eight scenes, 16 samples of the teapot 0.9990, RMSE
 0.18 % of the mean): >= 99.8 % of the pixels of one sample agree to |d| <= 1e-4 + 1e-3*|ref| per
 channel; after 16 samples >= 99.5 % agree to 1e-3 + 2e-3*|ref| and the RMSE against the oracle's

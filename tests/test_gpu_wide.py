@@ -10,7 +10,7 @@ beyond the ray's t_max, which can only turn "occluded" into "free", for at most 
 shadow rays (an occluder within rounding of t_max, see pt_set_trace_mode).  Rendered film of one
 sample within |d| <= 1e-4 + 1e-3 |ref| of the oracle's film on >= 99.8 % of the pixels in mode 2 (measured:
 the same shares as mode 0, 0.9994 .. 1.0) and >= 99.5 % in mode 3 (measured 0.9964 .. 1.0; the lost
-occluders brighten a few pixels); profiles/r2_parity_report.json."""
+occluders brighten a few pixels); profiles/parity_report.json."""
 import numpy as np
 import pytest
 
