@@ -146,6 +146,21 @@ int pth_scene_set_integrator(pth_scene *s, int max_depth, int max_iterations) {
     s->scene.SetIntegrator(max_depth, max_iterations);
     return PT_OK;
 }
+int pth_scene_load(const char *path, pth_image_decoder decode, void *user, int width, int height, int max_depth, pth_scene **out) {
+    if (!path || !out) return Fail("pth_scene_load: null argument");
+    *out = nullptr;
+    pth_scene *s = new pth_scene();
+    const int st = Guard([&] {
+        s->scene.InitDefaults();
+        LoadSceneFile(s->scene, path, decode, user, width, height, max_depth);
+    });
+    if (st != PT_OK) {
+        delete s;
+        return st;
+    }
+    *out = s;
+    return PT_OK;
+}
 int pth_scene_set_camera(pth_scene *s, const float eye[3], const float look_at[3], const float up[3], float fovy_deg, int w, int h) {
     if (!s || !eye || !look_at || !up || w <= 0 || h <= 0) return Fail("pth_scene_set_camera: bad argument");
     Camera &c = s->scene.GetCamera();

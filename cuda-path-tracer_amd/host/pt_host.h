@@ -265,6 +265,12 @@ private:
     pt_ctx *m_ctx;
 };
 
+// Scene::LoadScene (scene.cpp:649-687) without the acceleration structures (host/scene_loader.cpp); the
+// decoder type is pth_image_decoder of include/ptamd_host.h.
+void LoadSceneFile(Scene &scene, const std::string &path,
+                   int (*decode)(void *, const uint8_t *, size_t, int, int *, int *, int *, uint8_t *, size_t), void *user,
+                   int width, int height, int max_depth);
+
 // Application::Run's offscreen branch (application.cpp:58-76) with progressive images and a film
 // checkpoint; see include/ptamd_host.h for the options.
 void RenderOffscreen(pt_ctx *ctx, Scene &scene, const struct pth_offscreen_options &options, struct pth_offscreen_result &result);

@@ -8,6 +8,7 @@ as integer addresses (e.g. ``tensor.data_ptr()``); nothing here allocates GPU me
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -141,15 +142,64 @@ def save_hdr(path: str, film: np.ndarray, iterations: int):
 
 
 # --------------------------------------------------------------------------- HostScene
-class HostScene:
-    """pth_scene: the host-side Scene of the facade (scene.h:23-186), filled programmatically."""
+def _pil_decoder():
+    """A pth_image_decoder backed by PIL: the C++ scene loader has no image decoder of its own."""
+    cache = {}
 
-    def __init__(self):
+    def decode(_user, data, n, want_channels, w, h, c, pixels, capacity):
+        try:
+            import io
+
+            from PIL import Image
+
+            key = (C.addressof(data.contents), n, want_channels)
+            if key not in cache:
+                cache.clear()
+                img = Image.open(io.BytesIO(C.string_at(data, n)))
+                if want_channels in (3, 4):
+                    img = img.convert("RGB" if want_channels == 3 else "RGBA")
+                px = np.asarray(img, dtype=np.uint8)
+                cache[key] = np.ascontiguousarray(px[:, :, None] if px.ndim == 2 else px)
+            px = cache[key]
+            w[0], h[0], c[0] = px.shape[1], px.shape[0], px.shape[2]
+            if pixels:
+                if capacity < px.size:
+                    return 2
+                C.memmove(pixels, px.ctypes.data, px.size)
+            return 0
+        except Exception:  # noqa: BLE001 - an exception must not cross the C boundary
+            return 1
+
+    return abi.IMAGE_DECODER(decode)
+
+
+class HostScene:
+    """pth_scene: the host-side Scene of the facade (scene.h:23-186), filled programmatically or
+    read from a scene file by the C++ loader (HostScene.load)."""
+
+    def __init__(self, _handle=None):
         self._lib = abi.load_library()
         self._h = C.c_void_p()
-        _host_check(self._lib.pth_scene_create(C.byref(self._h)))
+        if _handle is not None:
+            self._h = _handle
+        else:
+            _host_check(self._lib.pth_scene_create(C.byref(self._h)))
         self.width = self.height = 0
         self.max_depth, self.max_iterations = 4, 1000
+
+    @classmethod
+    def load(cls, path: str, width: int = 0, height: int = 0, max_depth: int = 0, ctx: "Context" = None, decode_images: bool = True) -> "HostScene":
+        """Scene::LoadScene (scene.cpp:649-687) through the C++ front end: scene JSON, glTF, OBJ.  Images are
+        decoded by PIL through a callback.  The scene comes back finalised (on the GPU behind `ctx` when given)."""
+        lib = abi.load_library()
+        h = C.c_void_p()
+        decoder = _pil_decoder() if decode_images else abi.IMAGE_DECODER()
+        _host_check(lib.pth_scene_load(os.fspath(path).encode(), decoder, None, int(width), int(height), int(max_depth), C.byref(h)))
+        hs = cls(_handle=h)
+        hs.finalize(ctx)
+        d = hs.desc()
+        hs.width, hs.height, hs.max_depth = d.camera.resolution[0], d.camera.resolution[1], d.max_depth
+        return hs
 
     def close(self):
         if self._h:

@@ -71,6 +71,22 @@ int pth_scene_get_desc(pth_scene *scene, pt_scene_desc *out);
 /* Scene::UpdateDevice (scene.cpp:52-96) */
 int pth_scene_update_device(pth_scene *scene, pt_ctx *ctx);
 
+/* ---- Scene::LoadScene (scene.cpp:649-687): scene JSON (current schema, and the older capitalised
+ * schema of Scenes/cornell.json etc. through this project's adapter), glTF 2.0 and Wavefront OBJ, read
+ * in C++ with the reference's id order (materials by key, one instance per glTF primitive per node,
+ * FACE_NORMALS de-indexing, T * Rx * Ry * Rz * S transforms).  The scene comes back filled but not
+ * finalised: finish with pth_scene_finalize or pth_scene_finalize_device.  width / height /
+ * max_depth > 0 override the file's values.
+ * Image files (PATH textures, glTF images) are decoded by the caller's callback, because no image
+ * decoder can be linked here; scenes without image textures may pass NULL.  The callback is called
+ * twice per image: first with pixels == NULL to report width, height and channel count, then with a
+ * buffer of width*height*channels bytes to fill (8 bits per channel, rows top to bottom).
+ * want_channels: 0 = as stored in the file, 3 = RGB, 4 = RGBA.  Non-zero return = failure.        */
+typedef int (*pth_image_decoder)(void *user, const uint8_t *file_bytes, size_t n_bytes, int want_channels, int *width,
+                                 int *height, int *channels, uint8_t *pixels, size_t capacity);
+int pth_scene_load(const char *path, pth_image_decoder decode, void *user, int width, int height, int max_depth,
+                   pth_scene **out);
+
 /* ---- PathIntegrator (kernel/integrators/path_trace.h:82-116) */
 int pth_integrator_create(pt_ctx *ctx, pth_integrator **out);
 void pth_integrator_destroy(pth_integrator *integrator);

@@ -1,0 +1,204 @@
+"""The C++ scene front end (pth_scene_load, host/scene_loader.cpp): scene JSON in both schemas, glTF 2.0
+and Wavefront OBJ read without any Python in the geometry / material path, images through the decode
+callback.  Checked against the Python reader of the cook step (cuda_path_tracer_amd.scene_io), which the
+tests of test_scene_io.py hold against what the reference's loader defines: every array of the
+finished scene (vertices, indices, instances with their matrices, BVHs, materials, lights, texture
+descriptors, image texels) must be equal byte for byte.  Where the reference's scene files are on the
+machine, the same holds against the cooked scenes that ship in scenes/.  On the GPU, a scene loaded
+this way renders the oracle's film."""
+import base64
+import ctypes as C
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+from test_scene_io import OBJ_NORMALS, OBJ_QUAD, _current_schema_scene, _tiny_gltf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _view(ptr, count, dtype):
+    if not count:
+        return np.zeros(0, dtype)
+    addr = ptr if isinstance(ptr, int) else C.cast(ptr, C.c_void_p).value
+    return np.frombuffer((C.c_char * (count * np.dtype(dtype).itemsize)).from_address(addr), dtype=dtype, count=count).copy()
+
+
+def _everything(hs):
+    """All arrays of a finished scene, texture pool included."""
+    out = dict(hs.arrays())
+    d = hs.desc()
+    out["textures1"] = _view(d.textures1, d.texture1_count * 32, np.uint8)
+    out["textures3"] = _view(d.textures3, d.texture3_count * 44, np.uint8)
+    for kind, images, count in (("images1", d.images1, d.image1_count), ("images3", d.images3, d.image3_count)):
+        for k in range(count):
+            im = images[k]
+            out[f"{kind}_{k}"] = _view(im.data, im.width * im.height * im.channels, np.float32)
+            out[f"{kind}_{k}_shape"] = (im.width, im.height, im.channels, im.srgb)
+    out["camera"] = bytes(d.camera)
+    out["max_depth"] = d.max_depth
+    return out
+
+
+def _assert_same(a, b):
+    assert a.keys() == b.keys()
+    for k, v in a.items():
+        if isinstance(v, np.ndarray):
+            assert np.ascontiguousarray(v).tobytes() == np.ascontiguousarray(b[k]).tobytes(), k
+        else:
+            assert v == b[k], k
+
+
+def _both(pt, path, **kw):
+    cpp = pt.HostScene.load(path, **kw)
+    py = pt.load_scene_json(path).build(width=kw.get("width") or None, height=kw.get("height") or None, max_depth=kw.get("max_depth") or None)
+    return _everything(cpp), _everything(py)
+
+
+def test_current_schema_obj_instances(pt, tmp_path):
+    a, b = _both(pt, _current_schema_scene(tmp_path))
+    _assert_same(a, b)
+    assert len(a["geometries"]) == 4 and a["geometries"]["material_id"].tolist() == [3, 0, 1, 1]
+    a, b = _both(pt, _current_schema_scene(tmp_path), width=48, height=20, max_depth=2)  # overrides reach the camera and the integrator
+    _assert_same(a, b)
+    assert a["max_depth"] == 2
+
+
+@pytest.mark.parametrize("with_normals", [True, False])
+def test_gltf_nodes_primitives_strides(pt, tmp_path, with_normals):
+    a, b = _both(pt, _tiny_gltf(tmp_path, with_normals))
+    _assert_same(a, b)
+    assert len(a["geometries"]) == 4 and len(a["blases"]) == 2
+
+
+def _png_bytes(arr):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(arr).save(buf, format="PNG")
+    return buf.getvalue()
+
+
+def _textured_scene(tmp_path):
+    """OBJ with file normals and FACE_NORMALS / INVERT_NORMALS variants, PATH textures (RGB albedo, grey
+    roughness, packed ORM) and a glTF whose materials carry embedded base-colour and metal-roughness images."""
+    rs = np.random.RandomState(5)
+    (tmp_path / "n.obj").write_text(OBJ_NORMALS)
+    (tmp_path / "quad.obj").write_text(OBJ_QUAD)
+    (tmp_path / "albedo.png").write_bytes(_png_bytes(rs.randint(0, 256, (6, 5, 3), dtype=np.uint8)))
+    (tmp_path / "grey.png").write_bytes(_png_bytes(rs.randint(0, 256, (4, 4), dtype=np.uint8)))
+    (tmp_path / "orm.png").write_bytes(_png_bytes(rs.randint(0, 256, (3, 7, 3), dtype=np.uint8)))
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]], np.float32)
+    uv = np.array([[0, 0], [1, 0], [0, 1], [1, 1]], np.float32)
+    idx = np.array([0, 1, 2, 1, 3, 2], np.uint32)
+    interleaved = np.concatenate([pos, uv], axis=1).astype(np.float32)  # byteStride 20: positions and uvs share a view
+    blob = interleaved.tobytes() + idx.tobytes()
+    base = _png_bytes(rs.randint(0, 256, (8, 8, 4), dtype=np.uint8))
+    mr = _png_bytes(rs.randint(0, 256, (5, 9, 3), dtype=np.uint8))
+    uri = lambda b, mime: f"data:{mime};base64," + base64.b64encode(b).decode()  # noqa: E731
+    g = {"asset": {"version": "2.0"}, "scenes": [{"nodes": [0]}],
+         "nodes": [{"mesh": 0, "matrix": [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0.5, 0.25, 0, 1]}],
+         "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "TEXCOORD_0": 1}, "indices": 2, "material": 0}]}],
+         "materials": [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}, "metallicRoughnessTexture": {"index": 1}}}],
+         "textures": [{"source": 0}, {"source": 1}],
+         "images": [{"uri": uri(base, "image/png")}, {"uri": uri(mr, "image/png")}],
+         "buffers": [{"byteLength": len(blob), "uri": uri(blob, "application/octet-stream")}],
+         "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 80, "byteStride": 20}, {"buffer": 0, "byteOffset": 80, "byteLength": 24}],
+         "accessors": [{"bufferView": 0, "componentType": 5126, "count": 4, "type": "VEC3"},
+                       {"bufferView": 0, "byteOffset": 12, "componentType": 5126, "count": 4, "type": "VEC2"},
+                       {"bufferView": 1, "componentType": 5125, "count": 6, "type": "SCALAR"}]}
+    (tmp_path / "t.gltf").write_text(json.dumps(g))
+    scene = {"integrator": {"DEPTH": 4, "ITERATIONS": 8},
+             "camera": {"EYE": [0.5, 0.8, 3], "LOOKAT": [0.5, 0.5, 0], "UP": [0, 1, 0], "FOVY": 50.0, "film": {"WIDTH": 40, "HEIGHT": 30}},
+             "materials": {"paint": {"TYPE": "diffuse", "ALBEDO": {"PATH": "albedo.png"}},
+                           "metal": {"TYPE": "metallic_roughness", "ALBEDO": {"RGB": [0.9, 0.8, 0.7]}, "ROUGHNESS": {"PATH": "grey.png"}, "METALLIC": {"VALUE": 1.0}},
+                           "packed": {"TYPE": "metallic_roughness", "ALBEDO": {"RGB": [0.5, 0.5, 0.5]}, "ORM": {"PATH": "orm.png"}},
+                           "lamp": {"TYPE": "emitting", "RADIANCE": {"RGB": [1, 0.9, 0.8], "EMITTANCE": 9.0}},
+                           "missing": {"TYPE": "diffuse", "ALBEDO": {"PATH": "no_such_file.png"}}},
+             "objects": [{"TYPE": "gltf", "PATH": "t.gltf", "SCALE": [1.5, 1.5, 1.5]},
+                         {"TYPE": "gltf", "PATH": "t.gltf", "MATERIAL": "metal", "TRANS": [-1.6, 0, 0], "FACE_NORMALS": True},
+                         {"TYPE": "obj", "PATH": "n.obj", "MATERIAL": "paint", "TRANS": [0, 0, -1], "INVERT_NORMALS": True},
+                         {"TYPE": "obj", "PATH": "quad.obj", "MATERIAL": "packed", "TRANS": [1.7, 0, 0], "FACE_NORMALS": True},
+                         {"TYPE": "obj", "PATH": "quad.obj", "MATERIAL": "missing", "TRANS": [0, -1.2, 0], "ROTAT": [-90, 0, 0], "SCALE": [4, 4, 1]},
+                         {"TYPE": "obj", "PATH": "quad.obj", "MATERIAL": "lamp", "TRANS": [0, 2.5, 1], "ROTAT": [90, 0, 0]}]}
+    path = tmp_path / "textured.json"
+    path.write_text(json.dumps(scene))
+    return str(path)
+
+
+def test_textures_images_and_normal_options(pt, tmp_path):
+    a, b = _both(pt, _textured_scene(tmp_path))
+    _assert_same(a, b)
+    # ids: lamp 1, metal 2, missing 3, packed 4, paint 5, then the first glTF object's material 6 and the second's 7
+    assert a["geometries"]["material_id"].tolist() == [6, 2, 5, 4, 3, 1]
+    assert a["images3_0_shape"] == (5, 6, 3, 1)                       # albedo.png: RGB, tagged sRGB like every albedo
+    assert a["images1_0_shape"] == (4, 4, 1, 0) and a["images1_1_shape"] == (7, 3, 1, 0)
+    assert len([k for k in a if k.startswith("images3_") and not k.endswith("shape")]) == 3  # albedo.png + the glTF base colour, loaded twice
+
+
+def test_legacy_schema_primitives(pt, tmp_path):
+    scene = {
+        "Materials": {"light": {"TYPE": "Emitting", "RGB": [1, 1, 1], "EMITTANCE": 5.0}, "white": {"TYPE": "Diffuse", "RGB": [0.98, 0.98, 0.98]},
+                      "shiny": {"TYPE": "Specular", "RGB": [0.9, 0.9, 0.9]}, "glass": {"TYPE": "RoughDielectric", "RGB": [1, 1, 1], "IOR": 1.45, "ROUGHNESS": 0.2},
+                      "gold": {"TYPE": "MetallicRoughness", "ALBEDO": [1.0, 0.8, 0.3], "METALLIC": 1.0, "ROUGHNESS": 0.25}},
+        "Camera": {"RES": [40, 30], "FOVY": 45.0, "ITERATIONS": 10, "DEPTH": 8, "EYE": [0, 5, 10], "LOOKAT": [0, 5, 0], "UP": [0, 1, 0]},
+        "Objects": [{"TYPE": "cube", "MATERIAL": "light", "TRANS": [0, 10, 0], "ROTAT": [0, 0, 0], "SCALE": [3, 0.3, 3]},
+                    {"TYPE": "sphere", "MATERIAL": "shiny", "TRANS": [0, 2, 0], "ROTAT": [10, 20, 30], "SCALE": [2, 2, 2]},
+                    {"TYPE": "sphere", "MATERIAL": "glass", "TRANS": [3, 2, 0], "SCALE": [1, 2, 1]},
+                    {"TYPE": "cube", "MATERIAL": "gold", "TRANS": [-3, 1, 0], "ROTAT": [0, 45, 0]},
+                    {"TYPE": "cube", "MATERIAL": "white", "TRANS": [0, 0, 0], "ROTAT": [0, 0, 0], "SCALE": [10, 0.01, 10]}],
+    }
+    path = tmp_path / "legacy.json"
+    path.write_text(json.dumps(scene))
+    a, b = _both(pt, str(path))
+    _assert_same(a, b)
+    assert a["max_depth"] == 8 and a["geometries"]["material_id"].tolist() == [3, 4, 1, 2, 5]
+
+
+def test_loader_errors_are_reported(pt, tmp_path):
+    with pytest.raises(pt.PtError, match="could not open"):
+        pt.HostScene.load(str(tmp_path / "absent.json"))
+    bad = tmp_path / "bad.json"
+    bad.write_text('{"camera": {"film": {"WIDTH": 4, "HEIGHT": 4}}, "objects": [}')
+    with pytest.raises(pt.PtError, match="JSON"):
+        pt.HostScene.load(str(bad))
+    nocam = tmp_path / "nocam.json"
+    nocam.write_text('{"materials": {}, "objects": []}')
+    with pytest.raises(pt.PtError, match="camera"):
+        pt.HostScene.load(str(nocam))
+    with pytest.raises(pt.PtError, match="no image decoder"):
+        pt.HostScene.load(_textured_scene(tmp_path), decode_images=False)
+
+
+@pytest.mark.parametrize("name,rel", [("teapot", "teapot/teapot.json"), ("cornell", "cornell.json"), ("pbr_metallic", "pbr_metallic.json"),
+                                      ("pbr_ior", "pbr_ior.json"), ("sphere", "sphere.json"), ("helmet", "helmet/helmet.json")])
+def test_reference_scene_files_load_to_the_cooked_scenes(pt, name, rel):
+    """Where the reference's Scenes/ directory is on the machine, its files read by the C++ front end give,
+    byte for byte, the scenes the GPU tests and the bench use (scenes/*.npz, cooked by the Python reader)."""
+    src = os.path.join("/root/reference/Scenes", rel)
+    if not os.path.exists(src):
+        pytest.skip("reference scene files are not on this machine")
+    cooked = pt.SceneSpec.load(os.path.join(ROOT, "scenes", name + ".npz")).build(width=64, height=48)
+    _assert_same(_everything(pt.HostScene.load(src, width=64, height=48)), _everything(cooked))
+
+
+@pytest.mark.gpu
+def test_scene_loaded_in_cpp_renders_the_oracle_film(pt, ora, gpu_ctx, tmp_path):
+    path = _textured_scene(tmp_path)
+    hs = pt.HostScene.load(path, ctx=gpu_ctx)  # BVHs built on the GPU as well
+    _assert_same(_everything(hs), _everything(pt.HostScene.load(path)))
+    w, h = hs.width, hs.height
+    assert (w, h, hs.max_depth) == (40, 30, 4)
+    desc = hs.desc()
+    gpu_ctx.upload(desc)
+    gpu_ctx.integrator_init(w, h)
+    ref = None
+    for it in range(4):
+        gpu_ctx.render(w, h, it)
+        ref, _ = ora.render(desc, w, h, it, ref, nthreads=4)
+    film = gpu_ctx.film_download(w, h)
+    assert ref.mean() > 1e-3 and np.isfinite(film).all()
+    close = (np.abs(film - ref) <= 1e-4 + 1e-3 * np.abs(ref)).all(axis=2)
+    assert close.mean() >= 0.99, close.mean()
