@@ -92,10 +92,15 @@ struct DTex {
     // without a third dependent load (null when image_id is out of range)
     const void *img_data;
     int32_t img_width, img_height;
+    int32_t filter, _pad;  // kTexFixedPointWeights | kTexSrgbDecode, as chosen with pt_set_texture_filter before the upload
 };
+// Options of the software texture filter that stands in for the CUDA texture unit (texture.cpp:60-69).
+constexpr int32_t kTexFixedPointWeights = 1;  // bilinear weights rounded to 8 fractional bits, as the CUDA unit stores them
+constexpr int32_t kTexSrgbDecode = 2;         // texels of images tagged sRGB are linearised before filtering
 struct DImage {
     const void *data;  // float (1 channel) or float4 (3 channels + padding)
     int32_t width, height;
+    int32_t filter, _pad;  // as DTex::filter
 };
 struct DAlias {
     const float *prob;

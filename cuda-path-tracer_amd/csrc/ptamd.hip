@@ -139,6 +139,7 @@ struct pt_ctx {
     std::vector<EventPair> free_events;
     pt_stats stats;
     int trace_mode = 0;
+    int texture_filter = 0;  // kTexFixedPointWeights | kTexSrgbDecode, applied by the next pt_scene_upload
     bool host_may_block = false;  // set by the synchronous entry points around RunBounces
 };
 
@@ -564,6 +565,13 @@ int pt_set_trace_mode(pt_ctx *ctx, int mode) {
     return PT_OK;
 }
 
+int pt_set_texture_filter(pt_ctx *ctx, int options) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (options < 0 || options > 3) return Fail(ctx, PT_ERR_INVALID, "texture filter options %d (bit 0: 8-bit fixed-point weights, bit 1: sRGB decode of tagged images)", options);
+    ctx->texture_filter = options;
+    return PT_OK;
+}
+
 int pt_reset_stats(pt_ctx *ctx) {
     if (!ctx) return PT_ERR_INVALID;
     DeviceGuard guard(ctx->device);
@@ -855,7 +863,7 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
         const float *dev = nullptr;
         st = Upload(ctx, ctx->scene_allocs, im.data, size_t(im.width) * im.height, &dev);
         if (st != PT_OK) return st;
-        img1[i] = DImage{dev, im.width, im.height};
+        img1[i] = DImage{dev, im.width, im.height, ctx->texture_filter & kTexFixedPointWeights, 0};
     }
     for (uint32_t i = 0; i < d->image3_count; ++i) {
         const pt_image &im = d->images3[i];
@@ -865,19 +873,21 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
         const float4 *dev = nullptr;
         st = Upload(ctx, ctx->scene_allocs, rgba.data(), rgba.size(), &dev);
         if (st != PT_OK) return st;
-        img3[i] = DImage{dev, im.width, im.height};
+        img3[i] = DImage{dev, im.width, im.height, (ctx->texture_filter & kTexFixedPointWeights) | ((im.srgb && (ctx->texture_filter & kTexSrgbDecode)) ? kTexSrgbDecode : 0), 0};
     }
     for (DTex &t : tex1)
         if (t.type == PT_TEX_IMAGE && t.image_id >= 0 && uint32_t(t.image_id) < d->image1_count) {
             t.img_data = img1[t.image_id].data;
             t.img_width = img1[t.image_id].width;
             t.img_height = img1[t.image_id].height;
+            t.filter = img1[t.image_id].filter;
         }
     for (DTex &t : tex3)
         if (t.type == PT_TEX_IMAGE && t.image_id >= 0 && uint32_t(t.image_id) < d->image3_count) {
             t.img_data = img3[t.image_id].data;
             t.img_width = img3[t.image_id].width;
             t.img_height = img3[t.image_id].height;
+            t.filter = img3[t.image_id].filter;
         }
 
     // ---- alias tables

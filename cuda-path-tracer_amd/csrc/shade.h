@@ -23,7 +23,10 @@ struct Isect {  // Intersection, kernel/intersection.h:10-17
 // unit, so the filter is defined in software, in fp32:
 //   x = s*W - 0.5, i0 = floor(x), fx = x - i0, columns i0 mod W and (i0+1) mod W (rows alike),
 //   value = lerp_y(lerp_x(T00,T10), lerp_x(T01,T11)), lerp(a,b,f) = a*(1-f) + b*f.
-// Non-finite coordinates return 0.  The sRGB tag of albedo images is not applied (fp32 texels).
+// Non-finite coordinates return 0.  Two properties of the CUDA unit are open questions without a CUDA
+// device to ask, and are options (pt_set_texture_filter) rather than guesses: its bilinear weights
+// have 8 fractional bits, and it may or may not linearise fp32 texels of a texture flagged sRGB
+// (texture.cpp:67-69 sets the flag on float4 albedo images).  Default: fp32 weights, no decode.
 PTD int wrapi(int i, int n) {
     int m = i % n;
     return m < 0 ? m + n : m;
@@ -34,10 +37,19 @@ PTD void bilinear_setup(const DImage &img, float s, float t, int &i0, int &i1, i
     const float fx0 = floorf(x), fy0 = floorf(y);
     fx = x - fx0;
     fy = y - fy0;
+    if (img.filter & kTexFixedPointWeights) {
+        fx = floorf(fx * 256.0f + 0.5f) * (1.0f / 256.0f);
+        fy = floorf(fy * 256.0f + 0.5f) * (1.0f / 256.0f);
+    }
     i0 = (fabsf(fx0) < 1.0e9f) ? wrapi(int(fx0), img.width) : 0;
     j0 = (fabsf(fy0) < 1.0e9f) ? wrapi(int(fy0), img.height) : 0;
     i1 = (i0 + 1 == img.width) ? 0 : i0 + 1;
     j1 = (j0 + 1 == img.height) ? 0 : j0 + 1;
+}
+PTD float srgb_to_linear(float c) { return c <= 0.04045f ? c * (1.0f / 12.92f) : powf((c + 0.055f) * (1.0f / 1.055f), 2.4f); }
+PTD float4 srgb_decode(float4 t, int32_t filter) {
+    if (!(filter & kTexSrgbDecode)) return t;
+    return make_float4(srgb_to_linear(t.x), srgb_to_linear(t.y), srgb_to_linear(t.z), t.w);
 }
 PTD float lerp2(float t00, float t10, float t01, float t11, float fx, float fy) {
     const float a = t00 * (1.0f - fx) + t10 * fx;
@@ -50,8 +62,8 @@ PTD V3 sample_image3(const DImage &img, float s, float t) {
     float fx, fy;
     bilinear_setup(img, s, t, i0, i1, j0, j1, fx, fy);
     const float4 *d = static_cast<const float4 *>(img.data);
-    const float4 t00 = d[size_t(j0) * img.width + i0], t10 = d[size_t(j0) * img.width + i1];
-    const float4 t01 = d[size_t(j1) * img.width + i0], t11 = d[size_t(j1) * img.width + i1];
+    const float4 t00 = srgb_decode(d[size_t(j0) * img.width + i0], img.filter), t10 = srgb_decode(d[size_t(j0) * img.width + i1], img.filter);
+    const float4 t01 = srgb_decode(d[size_t(j1) * img.width + i0], img.filter), t11 = srgb_decode(d[size_t(j1) * img.width + i1], img.filter);
     return mk3(lerp2(t00.x, t10.x, t01.x, t11.x, fx, fy), lerp2(t00.y, t10.y, t01.y, t11.y, fx, fy),
                lerp2(t00.z, t10.z, t01.z, t11.z, fx, fy));
 }
@@ -76,7 +88,7 @@ PTD V3 sample_tex3(const DScene &S, int id, V2 uv) {
     }
     if (t.type == PT_TEX_IMAGE) {
         if (!t.img_data) return splat(0.0f);
-        return sample_image3(DImage{t.img_data, t.img_width, t.img_height}, s, tt);
+        return sample_image3(DImage{t.img_data, t.img_width, t.img_height, t.filter, 0}, s, tt);
     }
     return splat(0.0f);
 }
@@ -92,7 +104,7 @@ PTD float sample_tex1(const DScene &S, int id, V2 uv) {
     }
     if (t.type == PT_TEX_IMAGE) {
         if (!t.img_data) return 0.0f;
-        return sample_image1(DImage{t.img_data, t.img_width, t.img_height}, s, tt);
+        return sample_image1(DImage{t.img_data, t.img_width, t.img_height, t.filter, 0}, s, tt);
     }
     return 0.0f;
 }
@@ -434,12 +446,14 @@ struct TexPlan {
     int mode;  // 0: value 0, 1: c0, 2: c1, 3: image (four taps at the offsets below)
     uint32_t o00, o10, o01, o11;
     float fx, fy;
+    int32_t filter;
 };
 PTD TexPlan tex_plan(const DTex &t, bool valid, V2 uv) {
     TexPlan p;
     p.mode = 0;
     p.o00 = p.o10 = p.o01 = p.o11 = 0;
     p.fx = p.fy = 0.0f;
+    p.filter = 0;
     if (!valid) return p;
     if (t.type == PT_TEX_CONSTANT) {
         p.mode = 1;
@@ -455,7 +469,8 @@ PTD TexPlan tex_plan(const DTex &t, bool valid, V2 uv) {
     if (t.type != PT_TEX_IMAGE || !t.img_data) return p;
     if (!isfinite(s) || !isfinite(tt) || t.img_width <= 0 || t.img_height <= 0) return p;
     int i0, i1, j0, j1;
-    bilinear_setup(DImage{t.img_data, t.img_width, t.img_height}, s, tt, i0, i1, j0, j1, p.fx, p.fy);
+    bilinear_setup(DImage{t.img_data, t.img_width, t.img_height, t.filter, 0}, s, tt, i0, i1, j0, j1, p.fx, p.fy);
+    p.filter = t.filter;
     p.o00 = uint32_t(j0) * uint32_t(t.img_width) + uint32_t(i0);
     p.o10 = uint32_t(j0) * uint32_t(t.img_width) + uint32_t(i1);
     p.o01 = uint32_t(j1) * uint32_t(t.img_width) + uint32_t(i0);
@@ -466,9 +481,11 @@ PTD TexPlan tex_plan(const DTex &t, bool valid, V2 uv) {
 PTD V3 tex3_value(const TexPlan &p, const DTex &t, float4 t00, float4 t10, float4 t01, float4 t11) {
     if (p.mode == 1) return mk3(t.c0[0], t.c0[1], t.c0[2]);
     if (p.mode == 2) return mk3(t.c1[0], t.c1[1], t.c1[2]);
-    if (p.mode == 3)
+    if (p.mode == 3) {
+        t00 = srgb_decode(t00, p.filter); t10 = srgb_decode(t10, p.filter); t01 = srgb_decode(t01, p.filter); t11 = srgb_decode(t11, p.filter);
         return mk3(lerp2(t00.x, t10.x, t01.x, t11.x, p.fx, p.fy), lerp2(t00.y, t10.y, t01.y, t11.y, p.fx, p.fy),
                    lerp2(t00.z, t10.z, t01.z, t11.z, p.fx, p.fy));
+    }
     return splat(0.0f);
 }
 PTD float tex1_value(const TexPlan &p, const DTex &t, float t00, float t10, float t01, float t11) {
@@ -498,9 +515,11 @@ PTD TexReq tex_request(const DTex *table, uint32_t count, int id, V2 uv) {
     return r;
 }
 PTD V3 tex3_finish(const TexReq &r, float4 t00, float4 t10, float4 t01, float4 t11) {
-    if (r.p.mode == 3)
+    if (r.p.mode == 3) {
+        t00 = srgb_decode(t00, r.p.filter); t10 = srgb_decode(t10, r.p.filter); t01 = srgb_decode(t01, r.p.filter); t11 = srgb_decode(t11, r.p.filter);
         return mk3(lerp2(t00.x, t10.x, t01.x, t11.x, r.p.fx, r.p.fy), lerp2(t00.y, t10.y, t01.y, t11.y, r.p.fx, r.p.fy),
                    lerp2(t00.z, t10.z, t01.z, t11.z, r.p.fx, r.p.fy));
+    }
     return r.cval;  // zero when the lookup is invalid
 }
 PTD float tex1_finish(const TexReq &r, float t00, float t10, float t01, float t11) {

@@ -402,6 +402,11 @@ class Context:
         t_max; bit 1: 4-wide BVH nodes, rebuilt top level, searches bounded across instances."""
         self._check(self._lib.pt_set_trace_mode(self._h, int(mode)))
 
+    def set_texture_filter(self, options: int):
+        """Bit 0: bilinear weights with 8 fractional bits (as the CUDA texture unit); bit 1: sRGB decode of
+        images tagged sRGB.  Applied by the next upload."""
+        self._check(self._lib.pt_set_texture_filter(self._h, int(options)))
+
     def set_profiling(self, on: bool):
         self._check(self._lib.pt_set_profiling(self._h, int(on)))
 

@@ -117,7 +117,7 @@ typedef struct pt_texture3 {
 typedef struct pt_image {
     const float *data;
     int32_t width, height, channels;
-    int32_t srgb; /* ColorSpace::sRGB tag; carried, not applied to fp32 texels */
+    int32_t srgb; /* ColorSpace::sRGB tag; applied only with PT_TEX_SRGB_DECODE (pt_set_texture_filter) */
 } pt_image;
 
 /* DeviceDiscreteSampler1D, kernel/device_types.h:122-127 (host pointers here). */
@@ -281,6 +281,16 @@ int pt_reset_stats(pt_ctx *ctx);
  * Camera::UpdateDevice (camera.cpp:36-51): validates the description, re-packs
  * BVH / triangles / instances for gfx950 and uploads everything.             */
 int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *desc);
+/* Options of the software bilinear filter that replaces the CUDA texture object of the reference
+ * (texture.cpp:60-69: linear filter, wrap addressing, normalised coordinates, fp32 texels); they
+ * take effect at the next pt_scene_upload.  0 (default): fp32 weights from x = u*W - 0.5, texels as
+ * stored.  PT_TEX_FIXED_POINT_WEIGHTS: the two weights are rounded to 8 fractional bits, the
+ * precision the CUDA texture unit filters with.  PT_TEX_SRGB_DECODE: texels of images tagged srgb
+ * (the reference sets texture_desc.sRGB for albedo images, texture.cpp:67-69) are linearised before
+ * filtering; whether CUDA does that for float4 texels cannot be settled without a CUDA device, so it
+ * is off unless asked for.                                                                      */
+enum { PT_TEX_FIXED_POINT_WEIGHTS = 1, PT_TEX_SRGB_DECODE = 2 };
+int pt_set_texture_filter(pt_ctx *ctx, int options);
 /* Replaces Camera::UpdateDevice (camera.cpp:36-51) for a camera-only change. */
 int pt_camera_update(pt_ctx *ctx, const pt_camera *camera);
 /* Replaces Scene::~Scene / TLAS::FreeDevice / TexturePool::FreeDevice

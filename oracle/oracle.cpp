@@ -763,7 +763,10 @@ static inline Ray SpawnCameraRay(const pt_camera &c, int i, int j, float sx, flo
 //   x = s*W - 0.5, i0 = floor(x), fx = x - i0, texel columns i0 mod W and
 //   (i0+1) mod W (same for rows); value = lerp_y(lerp_x(T00,T10), lerp_x(T01,T11))
 //   with lerp(a,b,f) = a*(1-f) + b*f.  Non-finite coordinates return 0.
-// The sRGB tag of albedo images is carried but not applied (fp32 texels).
+// Two properties of the CUDA unit are options here as in the product (pt_set_texture_filter): bit 0
+// rounds the bilinear weights to 8 fractional bits, bit 1 linearises texels of images tagged sRGB.
+static int g_texture_filter = 0;
+static inline float SrgbToLinear(float c) { return c <= 0.04045f ? c * (1.0f / 12.92f) : powf((c + 0.055f) * (1.0f / 1.055f), 2.4f); }
 static inline int wrapi(int i, int n) {
     int m = i % n;
     return m < 0 ? m + n : m;
@@ -776,6 +779,11 @@ static inline void SampleImage(const pt_image &img, float s, float t, float *out
     float y = t * float(img.height) - 0.5f;
     float fx0 = floorf(x), fy0 = floorf(y);
     float fx = x - fx0, fy = y - fy0;
+    if (g_texture_filter & 1) {
+        fx = floorf(fx * 256.0f + 0.5f) * (1.0f / 256.0f);
+        fy = floorf(fy * 256.0f + 0.5f) * (1.0f / 256.0f);
+    }
+    const bool decode = CH == 3 && img.srgb && (g_texture_filter & 2);
     // coordinates beyond the int range wrap to texel 0 deterministically
     int i0 = (fabsf(fx0) < 1.0e9f) ? wrapi(int(fx0), img.width) : 0;
     int j0 = (fabsf(fy0) < 1.0e9f) ? wrapi(int(fy0), img.height) : 0;
@@ -787,6 +795,9 @@ static inline void SampleImage(const pt_image &img, float s, float t, float *out
         float t10 = d[(size_t(j0) * img.width + i1) * CH + c];
         float t01 = d[(size_t(j1) * img.width + i0) * CH + c];
         float t11 = d[(size_t(j1) * img.width + i1) * CH + c];
+        if (decode) {
+            t00 = SrgbToLinear(t00); t10 = SrgbToLinear(t10); t01 = SrgbToLinear(t01); t11 = SrgbToLinear(t11);
+        }
         float a = t00 * (1.0f - fx) + t10 * fx;
         float b = t01 * (1.0f - fx) + t11 * fx;
         out[c] = a * (1.0f - fy) + b * fy;
@@ -1845,6 +1856,8 @@ void ora_sample_texture3(const pt_scene_desc *desc, int texture_id, float u, flo
     rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
 }
 float ora_sample_texture1(const pt_scene_desc *desc, int texture_id, float u, float v) { return SampleTexture1(*desc, texture_id, {u, v}); }
+void ora_set_texture_filter(int options) { g_texture_filter = options; }
+
 // Math::PCG_Hash (math/hash.h:5-9) as the oracle restates it, for the known-answer vectors of the reference's own header.
 uint32_t ora_pcg_hash(uint32_t input) { return PCG_Hash(input); }
 

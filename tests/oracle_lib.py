@@ -68,6 +68,7 @@ def lib() -> C.CDLL:
         "ora_sample_texture1": (f32, [dp, i32, f32, f32]),
         "ora_pcg_stream": (None, [i32, i32, i32, i32, fp]),
         "ora_pcg_hash": (u32, [u32]),
+        "ora_set_texture_filter": (None, [i32]),
         "ora_stack_script": (u32, [up, i32, up]),
         "ora_camera_ray": (None, [C.POINTER(abi.Camera), i32, i32, f32, f32, fp, fp]),
     }
@@ -214,6 +215,16 @@ def debug_render(desc, w, h, state, nthreads=1):
     rgba = np.zeros((h, w, 4), np.uint8)
     lib().ora_debug_render(C.byref(desc), w, h, C.byref(state), abi.vptr(image), abi.vptr(rgba), nthreads)
     return image, rgba
+
+
+def sample_texture3(desc, texture_id, u, v):
+    out = np.zeros(3, np.float32)
+    lib().ora_sample_texture3(C.byref(desc), int(texture_id), float(u), float(v), abi.fptr(out))
+    return out
+
+
+def set_texture_filter(options: int):
+    lib().ora_set_texture_filter(int(options))
 
 
 def pcg_hash(values):

@@ -300,6 +300,35 @@ def test_light_without_geometry_samples_black(pt, ora, gpu_ctx, tiny_scene):
     assert film.mean() < gpu_ctx.film_download(w, h).mean()
 
 
+@pytest.mark.parametrize("options", [1, 2, 3])
+def test_texture_filter_options_match_oracle(pt, ora, gpu_ctx, scene_factory, options):
+    """pt_set_texture_filter: 8-bit fixed-point bilinear weights and / or sRGB decode of tagged images
+    change the textured helmet's film, and the oracle with the same options agrees with it."""
+    w, h = 128, 72
+    hs = scene_factory("helmet", w, h, 8)
+    desc = hs.desc()
+    gpu_ctx.upload(desc)
+    gpu_ctx.integrator_init(w, h)
+    gpu_ctx.render(w, h, 0)
+    default_film = gpu_ctx.film_download(w, h)
+    try:
+        gpu_ctx.set_texture_filter(options)
+        ora.set_texture_filter(options)
+        gpu_ctx.upload(desc)  # the options take effect at upload
+        gpu_ctx.render(w, h, 0)
+        film = gpu_ctx.film_download(w, h)
+        ref, _ = ora.render(desc, w, h, 0, nthreads=8)
+    finally:
+        gpu_ctx.set_texture_filter(0)
+        ora.set_texture_filter(0)
+        gpu_ctx.upload(desc)
+    assert (film != default_film).any(axis=2).mean() > 0.005  # most of this small frame is background
+    close = (np.abs(film - ref) <= 1e-4 + 1e-3 * np.abs(ref)).all(axis=2)
+    assert close.mean() >= 0.99, close.mean()
+    with pytest.raises(pt.PtError, match="texture filter"):
+        gpu_ctx.set_texture_filter(4)
+
+
 def test_passes_in_flight_shrink_when_path_state_does_not_fit(pt, gpu_ctx, scene_factory, monkeypatch):
     """With room for the path state of two passes in flight but not three, the third lane is
     retired and rendering goes on: same film, bit for bit.  A pass that does not fit even once is an

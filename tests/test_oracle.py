@@ -373,3 +373,43 @@ def test_oracle_stack_overflow_follows_the_reference_stack(pt, ora, depth, neare
     assert int(ref["prim"][0]) == prim
     true_nearest = depth if nearest_is_deepest else 0
     assert (prim == true_nearest) == (depth < 64 or not nearest_is_deepest)
+
+
+def test_texture_filter_options(pt, ora):
+    """The software filter's two options (8-bit fixed-point weights, sRGB decode of tagged images) as the
+    oracle defines them: the default is plain fp32 bilinear filtering of the stored texels."""
+    hs = pt.HostScene()
+    hs.set_camera([0, 0, 3], [0, 0, 0], [0, 1, 0], 45.0, 8, 8)
+    rs = np.random.RandomState(11)
+    texels = rs.rand(4, 4, 3).astype(np.float32)
+    tagged = hs.add_image_texture(hs.add_image(texels, srgb=True), 4, 4, 3)
+    plain = hs.add_image_texture(hs.add_image(texels, srgb=False), 4, 4, 3)
+    mat = hs.add_material(pt.abi.PT_MAT_LAMBERTIAN, tagged)
+    p = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    first = hs.add_mesh(p, np.tile([[0, 0, 1]], (3, 1)).astype(np.float32), p[:, :2].copy(), np.arange(3, dtype=np.uint32))
+    hs.add_instance(first, 3, 3, mat, np.eye(4, dtype=np.float32).reshape(-1), hs.new_blas_index())
+    hs.finalize()
+    desc = hs.desc()
+    try:
+        u, v = 0.3371, 0.6113  # x = u*4 - 0.5 = 0.8484: weight 0.8484 -> 217/256 = 0.84766 in fixed point
+        base = ora.sample_texture3(desc, tagged, u, v)
+        assert np.array_equal(base, ora.sample_texture3(desc, plain, u, v))
+        x, y = u * 4 - 0.5, v * 4 - 0.5
+        fx, fy = x - np.floor(x), y - np.floor(y)
+        i0, j0 = int(np.floor(x)), int(np.floor(y))
+        taps = texels[[j0, j0, j0 + 1, j0 + 1], [i0, i0 + 1, i0, i0 + 1]].astype(np.float64)
+
+        def bilinear(t, fx, fy):
+            return (t[0] * (1 - fx) + t[1] * fx) * (1 - fy) + (t[2] * (1 - fx) + t[3] * fx) * fy
+        assert np.allclose(base, bilinear(taps, fx, fy), atol=1e-6)
+        ora.set_texture_filter(1)
+        q = ora.sample_texture3(desc, tagged, u, v)
+        qx, qy = np.floor(fx * 256 + 0.5) / 256, np.floor(fy * 256 + 0.5) / 256
+        assert np.allclose(q, bilinear(taps, qx, qy), atol=1e-6) and not np.array_equal(q, base)
+        assert np.abs(q - base).max() <= 1.0 / 256
+        ora.set_texture_filter(2)
+        lin = np.where(taps <= 0.04045, taps / 12.92, ((taps + 0.055) / 1.055) ** 2.4)
+        assert np.allclose(ora.sample_texture3(desc, tagged, u, v), bilinear(lin, fx, fy), atol=1e-6)
+        assert np.array_equal(ora.sample_texture3(desc, plain, u, v), base)  # untagged images are never decoded
+    finally:
+        ora.set_texture_filter(0)
