@@ -36,11 +36,11 @@ def sq_binding(base):
     """What limits the closest-hit kernel, from the shader-engine counter passes of tools/profile_sq.sh."""
     vals = {}
     for name in "abc":
-        fs = glob.glob(os.path.join(base, name, "*", "*counter_collection.csv"))
-        if not fs:
+        f = newest(os.path.join(base, name, "*", "*counter_collection.csv"))
+        if not f:
             continue
         acc = defaultdict(list)
-        for r in csv.DictReader(open(fs[0])):
+        for r in csv.DictReader(open(f)):
             if short(r["Kernel_Name"]) != EXACT:
                 continue
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
