@@ -3,6 +3,7 @@
 import collections
 import csv
 import glob
+import os
 import sys
 
 kernel = sys.argv[1] if len(sys.argv) > 1 else "k_trace_closest<false, false>"
@@ -13,7 +14,7 @@ for name in "abc":
     if not fs:
         continue
     d = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(fs[0])):
+    for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
         if kernel not in r["Kernel_Name"]:
             continue
         d[r["Counter_Name"]][0] += 1
