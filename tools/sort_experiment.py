@@ -31,6 +31,7 @@ hits = torch.empty(n * 8, dtype=torch.float32, device=dev)
 def time_it(r, mode=0):
     ctx.set_trace_mode(mode)
     r = r.contiguous()
+    torch.cuda.synchronize()  # the gather runs on torch's stream, the query on the context's
     for _ in range(3):
         ctx.trace_closest(r.data_ptr(), n, hits.data_ptr())
     ctx.synchronize()
