@@ -69,6 +69,8 @@ def main():
                     help="iterations kept in flight per wavefront pass in the spp/s leg (about 0.5 GB of path state per sample at 1080p: three passes in flight)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--rays", default="captured", choices=["captured", "synthetic"])
+    ap.add_argument("--shard", default="samples", choices=["samples", "tiles"],
+                    help="how the spp leg is dealt out over ranks: iteration blocks of the whole frame, or all iterations of a band of rows")
     args = ap.parse_args()
 
     import torch
@@ -195,7 +197,7 @@ def main():
             t0 = time.perf_counter()
             # rank r owns the iteration blocks r, r+N, r+2N, ... of B consecutive iterations each; the job ends
             # with the films summed onto rank 0 (sharding.render_job)
-            pt.sharding.render_job(ctx, W, H, args.spp_steps * world, B, rank, world, film if reduce else None)
+            pt.sharding.render_job(ctx, W, H, args.spp_steps * world, B, rank, world, film if reduce else None, shard=args.shard)
             barrier()
             dt = pt.sharding.max_over_ranks(time.perf_counter() - t0, dev)
             ctx.set_trace_mode(0)
@@ -243,7 +245,7 @@ def main():
         spp = {"spp_per_s": spp_rate, "ms_per_spp": spp_elapsed * 1e3 / (args.spp_steps * world),
                "mpaths_per_s": spp_rate * W * H / 1e6,
                "rays_last_pass": {"closest": int(st2.closest_rays), "shadow": int(st2.shadow_rays)},
-               "iterations": args.spp_steps * world, "samples_in_flight": B,
+               "iterations": args.spp_steps * world, "samples_in_flight": B, "shard": args.shard,
                "spp_per_s_by_trace_mode": {"0": spp_rate, **other},
                "film_reduce": "rccl reduce(sum) to rank 0" if distributed else "none",
                "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,

@@ -146,7 +146,7 @@ PT_SYMBOLS = [
     "pt_ctx_create", "pt_ctx_destroy", "pt_last_error", "pt_version", "pt_set_stream", "pt_synchronize",
     "pt_set_profiling", "pt_get_stats", "pt_reset_stats", "pt_scene_upload", "pt_camera_update", "pt_scene_free",
     "pt_integrator_init", "pt_integrator_destroy", "pt_integrator_resize", "pt_integrator_reset", "pt_render",
-    "pt_render_async", "pt_render_batch", "pt_film_download", "pt_film_copy_to_device", "pt_film_copy_from_device", "pt_film_upload", "pt_display_download", "pt_tonemap",
+    "pt_render_async", "pt_render_batch", "pt_set_render_window", "pt_film_download", "pt_film_copy_to_device", "pt_film_copy_from_device", "pt_film_upload", "pt_display_download", "pt_tonemap",
     "pt_trace_closest", "pt_trace_any", "pt_resolve_hits", "pt_trace_closest_counted", "pt_trace_any_counted", "pt_trace_closest_static", "pt_trace_closest_host",
     "pt_trace_any_host", "pt_resolve_hits_host", "pt_generate_incoherent_rays", "pt_capture_bounce_rays", "pt_capture_shadow_rays",
     "pt_set_trace_mode", "pt_set_texture_filter", "pt_film_reduce", "pt_rccl_unique_id", "pt_rccl_comm_create", "pt_rccl_comm_destroy", "pt_debug_render", "pt_bvh_build", "pt_bvh_sizes", "pt_bvh_get", "pt_bvh_timing", "pt_bvh_free"]
@@ -208,6 +208,7 @@ def load_library() -> C.CDLL:
         "pt_render": (i32, [vp, i32, i32, i32, vp]),
         "pt_render_async": (i32, [vp, i32, i32, i32, vp]),
         "pt_render_batch": (i32, [vp, i32, i32, i32, i32, vp]),
+        "pt_set_render_window": (i32, [vp, i32, i32, i32, i32]),
         "pt_film_download": (i32, [vp, vp]),
         "pt_film_copy_to_device": (i32, [vp, vp]),
         "pt_film_copy_from_device": (i32, [vp, vp]),

@@ -52,7 +52,8 @@ struct PathState {
     uint32_t *ext_q[2];
     uint32_t *class_q[kNumClasses];
     uint32_t capacity;  // path slots = samples_in_flight * slots_per_sample
-    uint32_t slots_per_sample;  // pixels padded to 8x8 tiles
+    uint32_t slots_per_sample;  // pixels of the render window padded to 8x8 tiles
+    int win_x0, win_y0, win_w, win_h;  // the render window (pt_set_render_window): the pixels this context traces
 };
 
 // One atomic per wave: lanes with `pred` receive consecutive slots of the queue behind `counter`.
@@ -241,6 +242,15 @@ __global__ void k_gen_incoherent(DScene S, pt_ray *rays, uint32_t n, uint64_t fi
 // Path slot <-> pixel: slots are laid out in 8x8 pixel tiles (one tile per wave) so that the
 // camera rays of a wave form a compact bundle.  When several samples (iterations) are in flight
 // at once, sample k owns the slots [k * slots_per_sample, (k+1) * slots_per_sample).
+// The path pipeline lays its slots over the render window only; a pixel keeps its image coordinates
+// (and with them its sampler seed), so a window renders exactly what the full frame renders there.
+PTD bool slot_to_pixel(uint32_t slot, int width, int height, int &x, int &y);
+PTD bool slot_to_pixel(uint32_t slot, const PathState &P, int &x, int &y) {
+    const bool inside = slot_to_pixel(slot, P.win_w, P.win_h, x, y);
+    x += P.win_x0;
+    y += P.win_y0;
+    return inside;
+}
 PTD bool slot_to_pixel(uint32_t slot, int width, int height, int &x, int &y) {
     const uint32_t tiles_x = uint32_t(width + 7) >> 3;
     const uint32_t tiles_y = uint32_t(height + 7) >> 3;
@@ -255,7 +265,7 @@ PTD bool slot_to_pixel(uint32_t slot, int width, int height, int &x, int &y) {
 __global__ __launch_bounds__(64) void k_generate(DScene S, PathState P, BounceCounters *cnt, int first_iteration, int width, int height) {
     const uint32_t slot = blockIdx.x * kWave + threadIdx.x;
     int x, y;
-    const bool active = slot_to_pixel(slot, width, height, x, y);
+    const bool active = slot_to_pixel(slot, P, x, y);
     if (active) {
         const int iteration = first_iteration + int(slot / P.slots_per_sample);
         uint64_t rng = seed_sampler(x, y, iteration);
@@ -299,7 +309,7 @@ struct ExtendIO {
         } else {
             slot = i;
             int x, y;
-            if (!slot_to_pixel(slot, width, height, x, y)) return false;
+            if (!slot_to_pixel(slot, P, x, y)) return false;
         }
         const float4 ro = P.ray_o[slot], rd = P.ray_d[slot];
         o = mk3(ro.x, ro.y, ro.z);
@@ -778,7 +788,7 @@ __global__ __launch_bounds__(64) void k_shadow(DScene S, PathState P, BounceCoun
 __global__ __launch_bounds__(64) void k_film(PathState P, float *film, int width, int height, int samples, DevStats *stats) {
     const uint32_t slot = blockIdx.x * kWave + threadIdx.x;
     int x, y;
-    if (!slot_to_pixel(slot, width, height, x, y)) return;
+    if (!slot_to_pixel(slot, P, x, y)) return;
     float *px = film + 3 * (size_t(y) * width + x);
     float r = px[0], g = px[1], b = px[2];
     for (int k = 0; k < samples; ++k) {
@@ -823,8 +833,8 @@ __global__ void k_gather_rays(PathState P, const BounceCounters *cnt, int bounce
     if (bounce == 0) {  // camera rays: every path slot, written in pixel order
         slot = i;
         int x, y;
-        if (!slot_to_pixel(slot, width, height, x, y)) return;
-        i = uint32_t(y) * uint32_t(width) + uint32_t(x);
+        if (!slot_to_pixel(slot, P, x, y)) return;
+        i = uint32_t(y - P.win_y0) * uint32_t(P.win_w) + uint32_t(x - P.win_x0);  // pixel order inside the render window
     } else {
         slot = P.ext_q[bounce & 1][i];
     }

@@ -127,6 +127,7 @@ struct pt_ctx {
     hipEvent_t fork_event = nullptr;
     bool integrator_ready = false;
     int width = 0, height = 0;
+    int win[4] = {0, 0, 0, 0};  // render window x0, y0, w, h (pt_set_render_window); the whole frame after pt_integrator_init
     std::vector<void *> path_allocs;   // film, counters
     float *film = nullptr;
     uint32_t *pinned_word = nullptr;
@@ -603,7 +604,7 @@ int pt_get_stats(pt_ctx *ctx, pt_stats *out) {
         ctx->stats.bounces_run = 0;
         std::memset(ctx->stats.queue_sizes, 0, sizeof(ctx->stats.queue_sizes));
         // bounce 0 streams all path slots (8x8-tile padded); its real ray count is one per pixel
-        bc[0].ext_count = uint32_t(ctx->width) * uint32_t(ctx->height) * uint32_t(ctx->last_render_samples);
+        bc[0].ext_count = uint32_t(ctx->win[2]) * uint32_t(ctx->win[3]) * uint32_t(ctx->last_render_samples);
         for (int b = 0; b < ctx->last_render_bounces; ++b) {
             ctx->stats.closest_rays += bc[b].ext_count;
             ctx->stats.shadow_rays += bc[b].shadow_count;
@@ -1016,10 +1017,10 @@ static int EnsurePaths(pt_ctx *ctx, pt_ctx::Lane &l, uint32_t samples) {
     HIP_TRY(ctx, SyncAll(ctx));
     FreeAll(l.state_allocs);
     l.samples_alloc = 0;
-    const uint32_t tiles = uint32_t((ctx->width + 7) / 8) * uint32_t((ctx->height + 7) / 8);
+    const uint32_t tiles = uint32_t((ctx->win[2] + 7) / 8) * uint32_t((ctx->win[3] + 7) / 8);
     const size_t per_sample = size_t(tiles) * 64;
     const size_t cap = per_sample * samples;
-    if (cap >= (1ull << 31)) return Fail(ctx, PT_ERR_LIMIT, "%u samples in flight at %dx%d exceed 2^31 path slots", samples, ctx->width, ctx->height);
+    if (cap >= (1ull << 31)) return Fail(ctx, PT_ERR_LIMIT, "%u samples in flight at %dx%d exceed 2^31 path slots", samples, ctx->win[2], ctx->win[3]);
     PathState &P = l.paths;
     std::memset(&P, 0, sizeof(P));
     int st = PT_OK;
@@ -1042,11 +1043,15 @@ static int EnsurePaths(pt_ctx *ctx, pt_ctx::Lane &l, uint32_t samples) {
         std::memset(&P, 0, sizeof(P));
         (void)hipGetLastError();  // the failed allocation's error is reported here, not by a later launch check
         const std::string why = ctx->error;
-        return Fail(ctx, st, "path state for %u samples per pass at %dx%d (%.1f GB for each pass in flight) does not fit: %s", samples, ctx->width,
-                    ctx->height, double(cap) * 184.0 / 1e9, why.c_str());
+        return Fail(ctx, st, "path state for %u samples per pass at %dx%d (%.1f GB for each pass in flight) does not fit: %s", samples, ctx->win[2],
+                    ctx->win[3], double(cap) * 184.0 / 1e9, why.c_str());
     }
     P.capacity = uint32_t(cap);
     P.slots_per_sample = uint32_t(per_sample);
+    P.win_x0 = ctx->win[0];
+    P.win_y0 = ctx->win[1];
+    P.win_w = ctx->win[2];
+    P.win_h = ctx->win[3];
     l.samples_alloc = samples;
     return PT_OK;
 }
@@ -1082,6 +1087,9 @@ int pt_integrator_init(pt_ctx *ctx, int width, int height) {
     HIP_TRY(ctx, hipMemsetAsync(ctx->film, 0, size_t(width) * height * 3 * sizeof(float), ctx->stream));
     ctx->width = width;
     ctx->height = height;
+    ctx->win[0] = ctx->win[1] = 0;
+    ctx->win[2] = width;
+    ctx->win[3] = height;
     if ((st = EnsurePaths(ctx, ctx->lane[0], 1)) != PT_OK) return st;
     ctx->cur_lane = 0;
     ctx->integrator_ready = true;
@@ -1089,6 +1097,32 @@ int pt_integrator_init(pt_ctx *ctx, int width, int height) {
 }
 
 int pt_integrator_resize(pt_ctx *ctx, int width, int height) { return pt_integrator_init(ctx, width, height); }
+
+int pt_set_render_window(pt_ctx *ctx, int x0, int y0, int w, int h) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->integrator_ready) return Fail(ctx, PT_ERR_STATE, "pt_set_render_window before pt_integrator_init");
+    if (w == 0 && h == 0 && x0 == 0 && y0 == 0) {  // back to the whole frame
+        w = ctx->width;
+        h = ctx->height;
+    }
+    if (x0 < 0 || y0 < 0 || w <= 0 || h <= 0 || x0 > ctx->width - w || y0 > ctx->height - h)
+        return Fail(ctx, PT_ERR_INVALID, "render window %d,%d %dx%d does not lie inside the %dx%d frame", x0, y0, w, h, ctx->width, ctx->height);
+    if (x0 == ctx->win[0] && y0 == ctx->win[1] && w == ctx->win[2] && h == ctx->win[3]) return PT_OK;
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, SyncAll(ctx));
+    // path state is laid out over the window: every lane's is dropped and allocated again, for the new window, by its next pass
+    for (pt_ctx::Lane &l : ctx->lane) {
+        FreeAll(l.state_allocs);
+        l.samples_alloc = 0;
+        std::memset(&l.paths, 0, sizeof(l.paths));
+    }
+    for (bool &r : ctx->lane_retired) r = false;
+    ctx->win[0] = x0;
+    ctx->win[1] = y0;
+    ctx->win[2] = w;
+    ctx->win[3] = h;
+    return EnsurePaths(ctx, ctx->lane[0], 1);
+}
 
 int pt_integrator_reset(pt_ctx *ctx, int width, int height) {
     if (!ctx) return PT_ERR_INVALID;
@@ -1743,9 +1777,9 @@ int pt_capture_bounce_rays(pt_ctx *ctx, int width, int height, int iteration, in
     if (st != PT_OK) return st;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned_word, &l.counters[bounce].ext_count, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, SyncAll(ctx));
-    // bounce 0 streams every path slot (padded to 8x8 tiles) and writes the W*H camera rays in pixel order
+    // bounce 0 streams every path slot (padded to 8x8 tiles) and writes the render window's camera rays in pixel order
     const size_t launch_n = *ctx->pinned_word;
-    const size_t produced = bounce == 0 ? size_t(width) * size_t(height) : launch_n;
+    const size_t produced = bounce == 0 ? size_t(ctx->win[2]) * size_t(ctx->win[3]) : launch_n;
     if (produced > capacity) return Fail(ctx, PT_ERR_LIMIT, "capture buffer holds %zu rays, %zu needed", capacity, produced);
     if (launch_n > 0) {
         hipLaunchKernelGGL(k_gather_rays, dim3(uint32_t((launch_n + 255) / 256)), dim3(256), 0, ctx->stream, l.paths, l.counters, bounce, rays_device,

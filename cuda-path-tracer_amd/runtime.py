@@ -439,6 +439,10 @@ class Context:
         """`samples` iterations in one wavefront pass (asynchronous); film identical to separate renders."""
         self._check(self._lib.pt_render_batch(self._h, w, h, iteration, samples, C.c_void_p(rgba_device_ptr)))
 
+    def set_render_window(self, x0: int = 0, y0: int = 0, w: int = 0, h: int = 0):
+        """Restrict the render calls to a pixel window of the frame (all zero: the whole frame)."""
+        self._check(self._lib.pt_set_render_window(self._h, x0, y0, w, h))
+
     def film_download(self, w, h) -> np.ndarray:
         out = np.zeros((h, w, 3), np.float32)
         self._check(self._lib.pt_film_download(self._h, abi.vptr(out)))

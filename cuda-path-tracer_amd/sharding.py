@@ -4,6 +4,12 @@ A path depends only on (pixel, iteration) through its sampler seed
 (sampler/independent.h:14-23) and on read-only scene data; the film is the only shared mutable
 state and it is additive (path_trace.cu:391-407).  So iterations are dealt out to ranks in blocks
 and the private films are summed once at the end; no collective runs while rendering.
+
+The alternative is to deal out the image instead of the samples: every rank renders all iterations
+of its own band of rows (pt_set_render_window) and the same reduce assembles the frame, since films
+of disjoint windows add up to the full film.  Path state shrinks to a rank's share of the pixels, so
+this is the plan for frames whose path state would not fit one GPU; its load balance depends on the
+scene, where the sample plan's is perfect, so samples are the default.
 """
 from __future__ import annotations
 
@@ -22,6 +28,23 @@ def iteration_blocks(rank: int, world: int, total_iterations: int, block: int) -
     for b in range(rank, n_blocks, world):
         first = b * block
         out.append((first, min(block, total_iterations - first)))
+    return out
+
+
+def tile_windows(world: int, width: int, height: int) -> List[Tuple[int, int, int, int]]:
+    """(x0, y0, w, h) of every rank's window: bands of whole 8-pixel rows (the pipeline's path slots are
+    8x8 pixel tiles), heights differing by at most 8, together covering the frame exactly once.  A rank
+    beyond the number of 8-row strips gets an empty window (h = 0) and renders nothing."""
+    if world < 1 or width < 1 or height < 1:
+        raise ValueError("world, width and height must be positive")
+    strips = (height + 7) // 8
+    base, extra = divmod(strips, world)
+    out, row = [], 0
+    for r in range(world):
+        rows = min(height - row, 8 * (base + (1 if r < extra else 0)))
+        out.append((0, row, width, rows))
+        row += rows
+    assert row == height
     return out
 
 
@@ -49,17 +72,32 @@ def reduce_film(film, dst: int = 0):
     return film
 
 
-def render_job(ctx, width: int, height: int, total_iterations: int, block: int, rank: int, world: int, film=None):
-    """One rank's part of a sample-sharded render: clears its private film (only the rank that owns
-    iteration 0 would get that from pt_render_batch), submits its iteration blocks back to back, and,
+def render_job(ctx, width: int, height: int, total_iterations: int, block: int, rank: int, world: int, film=None, shard: str = "samples"):
+    """One rank's part of a sharded render: clears its private film (only the rank that owns
+    iteration 0 would get that from pt_render_batch), submits its passes back to back, and,
     given a device tensor `film` of W*H*3 fp32, ends with the one collective of the job: the private
     films summed onto rank 0 (`film` holds the sum there, and the context's film is replaced by it).
-    Returns the number of iterations this rank rendered."""
+    shard = "samples": the rank's iteration blocks of the whole frame; "tiles": every iteration of the
+    rank's band of rows.  Returns the number of iterations this rank rendered."""
+    if shard not in ("samples", "tiles"):
+        raise ValueError("shard must be 'samples' or 'tiles'")
     ctx.integrator_reset(width, height)
     done = 0
-    for first, count in iteration_blocks(rank, world, total_iterations, block):
-        ctx.render_batch(width, height, first, count)
-        done += count
+    if shard == "samples":
+        for first, count in iteration_blocks(rank, world, total_iterations, block):
+            ctx.render_batch(width, height, first, count)
+            done += count
+    else:
+        x0, y0, w, h = tile_windows(world, width, height)[rank]
+        if h > 0:
+            ctx.set_render_window(x0, y0, w, h)
+            try:
+                for first, count in iteration_blocks(0, 1, total_iterations, block):
+                    ctx.render_batch(width, height, first, count)
+                    done += count
+            finally:
+                ctx.synchronize()
+                ctx.set_render_window()
     ctx.synchronize()
     if film is not None:
         ctx.film_copy_to_device(film.data_ptr())

@@ -325,6 +325,16 @@ int pt_render_async(pt_ctx *ctx, int width, int height, int iteration, uint8_t *
  * one sample per call.                                                                       */
 int pt_render_batch(pt_ctx *ctx, int width, int height, int iteration, int samples, uint8_t *rgba_device);
 
+/* Restricts the path pipeline to the pixels [x0, x0+w) x [y0, y0+h) of the frame: the render calls
+ * above then trace, and add to the film, only those pixels, with path state and launches sized for
+ * the window.  A pixel keeps its frame coordinates, hence its sampler seed (kernel/sampler.h: the
+ * seed is a hash of x, y and the iteration), so a window's pixels are bit-identical to the same
+ * pixels of a full-frame render, and films of disjoint windows add up to the full film.  This is
+ * what image-tile sharding across GPUs rests on (every rank renders all iterations of its own
+ * tile; pt_film_reduce sums the films).  x0 = y0 = w = h = 0 selects the whole frame again, as
+ * pt_integrator_init does.  Waits for the passes in flight.  No counterpart in the reference.   */
+int pt_set_render_window(pt_ctx *ctx, int x0, int y0, int w, int h);
+
 /* Film access (the reference keeps m_image private; the headless path and the
  * multi-GPU reduce need it). rgb = W*H*3 fp32, row-major.                     */
 int pt_film_download(pt_ctx *ctx, float *rgb_host);

@@ -31,10 +31,19 @@ cam = pt.camera_make([0.0, 2.0, 6.0], [0.0, 1.0, 0.0], [0.0, 1.0, 0.0], 50.0, w,
 desc.camera = cam
 film = np.zeros((h, w, 3), np.float32)
 mine = []
-for first, count in pt.sharding.iteration_blocks(rank, world, total, block):
-    for it in range(first, first + count):
+if os.environ.get("PT_SHARD", "samples") == "samples":
+    for first, count in pt.sharding.iteration_blocks(rank, world, total, block):
+        for it in range(first, first + count):
+            film, _ = ora.render(desc, w, h, it, film, nthreads=2)
+            mine.append(it)
+else:  # tiles: every iteration of this rank's band of rows (the oracle renders whole frames; the band is cut out)
+    x0, y0, ww, hh = pt.sharding.tile_windows(world, w, h)[rank]
+    for it in range(total):
         film, _ = ora.render(desc, w, h, it, film, nthreads=2)
         mine.append(it)
+    band = np.zeros_like(film)
+    band[y0:y0 + hh, x0:x0 + ww] = film[y0:y0 + hh, x0:x0 + ww]
+    film = band
 np.save(os.path.join(os.environ["PT_OUT"], f"film_rank{rank}.npy"), film)
 t = torch.from_numpy(film.copy())
 pt.sharding.reduce_film(t, dst=0)
@@ -79,12 +88,29 @@ def test_rays_shard_covers_batch(pt):
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_two_rank_gloo_film_reduce(pt, ora, tiny_scene, tmp_path):
+def test_tile_windows_partition_the_frame(pt):
+    for world in (1, 2, 3, 8, 16):
+        for width, height in ((16, 10), (1920, 1080), (3840, 2160), (7, 5), (64, 64)):
+            wins = pt.sharding.tile_windows(world, width, height)
+            assert len(wins) == world
+            covered = np.zeros((height, width), np.int32)
+            for x0, y0, w, h in wins:
+                assert x0 == 0 and w == width and h >= 0 and y0 % 8 == 0 or h == 0
+                covered[y0:y0 + h, x0:x0 + w] += 1
+            assert (covered == 1).all()
+            heights = [h for _, _, _, h in wins]
+            if height >= 8 * world:
+                assert max(heights) - min(heights) <= 8
+    with pytest.raises(ValueError):
+        pt.sharding.tile_windows(0, 8, 8)
+
+
+def _run_two_ranks(tmp_path, shard):
     port = _free_port()
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   PT_ROOT=ROOT, PT_OUT=str(tmp_path), OMP_NUM_THREADS="2")
+                   PT_ROOT=ROOT, PT_OUT=str(tmp_path), OMP_NUM_THREADS="2", PT_SHARD=shard)
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
     for p in procs:
@@ -96,6 +122,26 @@ def test_two_rank_gloo_film_reduce(pt, ora, tiny_scene, tmp_path):
             raise
         outs.append(out.decode())
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+
+def test_two_rank_gloo_tile_sharded_film_reduce(pt, ora, tiny_scene, tmp_path):
+    """Image-tile plan: each rank holds every iteration of its own band of rows and zeros elsewhere, so the
+    reduced film equals the single-process film bit for bit (every pixel has one non-zero addend)."""
+    _run_two_ranks(tmp_path, "tiles")
+    w, h = 32, 24
+    f0, f1 = np.load(tmp_path / "film_rank0.npy"), np.load(tmp_path / "film_rank1.npy")
+    assert (f0[16:] == 0).all() and (f1[:16] == 0).all() and f0[:16].any() and f1[16:].any()
+    reduced = np.load(tmp_path / "film_reduced.npy")
+    desc = tiny_scene.desc()
+    desc.camera = pt.camera_make([0.0, 2.0, 6.0], [0.0, 1.0, 0.0], [0.0, 1.0, 0.0], 50.0, w, h)
+    film = np.zeros((h, w, 3), np.float32)
+    for it in range(7):
+        film, _ = ora.render(desc, w, h, it, film, nthreads=4)
+    assert np.array_equal(reduced.view(np.uint32), film.view(np.uint32))
+
+
+def test_two_rank_gloo_film_reduce(pt, ora, tiny_scene, tmp_path):
+    _run_two_ranks(tmp_path, "samples")
 
     iters = [list(map(int, open(tmp_path / f"iters_rank{r}.txt").read().split())) for r in range(2)]
     assert iters[0] == [0, 1, 4, 5] and iters[1] == [2, 3, 6]
