@@ -80,17 +80,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PT_BENCH_BACKEND=gloo rehearses the N > 1 code path where the ranks cannot each have a GPU of their own
+    # (RCCL refuses two ranks on one device): ranks then share the visible GPUs and the collectives run on the host
+    backend = os.environ.get("PT_BENCH_BACKEND", "nccl")
+    device_index = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")  # where the small bookkeeping collectives live
     if distributed:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     import cuda_path_tracer_amd as pt
 
     W, H = args.width, args.height
     spec = pt.SceneSpec.load(os.path.join(ROOT, "scenes", args.scene + ".npz"))
     hs = spec.build(width=W, height=H)
-    ctx = pt.Context(local_rank)
+    ctx = pt.Context(device_index)
     hs.update_device(ctx)
     ctx.integrator_init(W, H)
     depth = hs.max_depth
@@ -142,7 +150,7 @@ def main():
     def total_over_ranks(x):
         if not distributed:
             return x
-        t = torch.tensor([x], dtype=torch.int64, device=dev)
+        t = torch.tensor([x], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return int(t.item())
 
@@ -163,7 +171,7 @@ def main():
         ctx.set_profiling(False)
         st = ctx.stats()
         ctx.set_trace_mode(0)
-        return pt.sharding.max_over_ranks(dt, dev), st.ms_closest / max(1, st.n_closest), int(st.n_closest)
+        return pt.sharding.max_over_ranks(dt, coll_dev), st.ms_closest / max(1, st.n_closest), int(st.n_closest)
 
     total_rays = total_over_ranks(n_rays)
     wide_elapsed, wide_kernel_ms, _ = closest_leg(2)
@@ -199,7 +207,7 @@ def main():
             # with the films summed onto rank 0 (sharding.render_job)
             pt.sharding.render_job(ctx, W, H, args.spp_steps * world, B, rank, world, film if reduce else None, shard=args.shard)
             barrier()
-            dt = pt.sharding.max_over_ranks(time.perf_counter() - t0, dev)
+            dt = pt.sharding.max_over_ranks(time.perf_counter() - t0, coll_dev)
             ctx.set_trace_mode(0)
             return dt
 
@@ -247,7 +255,7 @@ def main():
                "rays_last_pass": {"closest": int(st2.closest_rays), "shadow": int(st2.shadow_rays)},
                "iterations": args.spp_steps * world, "samples_in_flight": B, "shard": args.shard,
                "spp_per_s_by_trace_mode": {"0": spp_rate, **other},
-               "film_reduce": "rccl reduce(sum) to rank 0" if distributed else "none",
+               "film_reduce": (("rccl" if backend == "nccl" else backend + " (rehearsal, staged through the host)") + " reduce(sum) to rank 0") if distributed else "none",
                "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                             "A_sample_bytes_per_pixel": sample_bytes / P, "A_sample_streamed_bytes_per_pixel": streamed_bytes / P,
                             "rays_per_pixel": {"closest": n_ext / P, "shadow": n_sh / P},
