@@ -470,15 +470,23 @@ int pt_capture_bounce_rays(pt_ctx *ctx, int width, int height, int iteration, in
                            pt_ray *rays_device, size_t capacity, size_t *count);
 
 /* Captures the shadow rays (next-event estimation, path_trace.cu:221-243) that the shading of
- * `bounce` emits in `iteration`, with their t_max = distance - 1e-4, in queue order.          */
+ * `bounce` emits in `iteration`, with their t_max = distance - 1e-5, in queue order.          */
 int pt_capture_shadow_rays(pt_ctx *ctx, int width, int height, int iteration, int bounce,
                            pt_ray *rays_device, size_t capacity, size_t *count);
 
-/* Traversal variant, two independent bits; 0 (default) answers every query exactly like the reference.
- * Bit 0 (modes 1, 3): any-hit searches (pt_trace_any, shadow rays) skip boxes that start beyond the
- *   ray's t_max, which the reference does not do (kernel/intersection.h:120-121,209-210 test child
- *   boxes against FLT_MAX): fewer nodes are visited, and "occluded" can turn into "free" where a
- *   triangle lies within rounding of t_max (never the other way round).
+/* Traversal variant, two independent bits; 0 (default) answers every query exactly like the reference,
+ * including what its any-hit search does after the first accepted triangle: it finishes the instance
+ * (boxes tested against the latest accepted distance) and reports a hit only if the world-space distance
+ * recomputed from the last accepted triangle is not negative (kernel/intersection.h:101-109, :139-149).
+ * Bit 0 (modes 1, 3): any-hit searches (pt_trace_any, shadow rays) stop at the first accepted triangle
+ *   farther than 1e-2 (nearer ones follow the rule above, so a triangle touching the ray's origin is
+ *   judged as in the reference) and skip boxes that start beyond t_max * (1 + 2^-12), which the reference
+ *   does not do (kernel/intersection.h:120-121,209-210 test child boxes against FLT_MAX): fewer nodes are
+ *   visited (2.5x faster shadow rays in the 20 001-instance scene).  A box test and a triangle test round
+ *   differently, so in principle "occluded" can turn into "free" for a triangle within rounding of t_max;
+ *   the margin keeps the decision with the triangle test where the reference's own shadow rays put
+ *   geometry exactly there (the sampled light, path_trace.cu:314-318).  Measured against the CPU oracle
+ *   on 2.1 M captured shadow rays of three scenes and against mode 0 on 17.6 M of five: no flag differs.
  * Bit 1 (modes 2, 3): the trees are walked as 4-wide nodes (128 bytes: the reference's own fp32 boxes
  *   of four children, tested with the reference's arithmetic), the top level is rebuilt top down over
  *   the reference's instance boxes, and the search inside an instance is bounded by the best hit of

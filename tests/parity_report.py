@@ -43,7 +43,7 @@ def main():
             ref, _ = ora.render(desc, w, h, it, ref, nthreads=16)
             refs.append(ref.copy())
         rec = {"resolution": [w, h], "depth": depth}
-        for mode in (0, 2, 3):
+        for mode in (0, 1, 2, 3):
             ctx.set_trace_mode(mode)
             ctx.render(w, h, 0)
             one = ctx.film_download(w, h)

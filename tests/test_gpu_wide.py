@@ -6,11 +6,10 @@ Bar for these modes: closest-hit primitive / instance ids equal to the oracle's 
 triangle test on the same triangle record, so wherever the ids agree the distance and the
 barycentrics are in fact bit-equal, which the tests also require).  Any-hit flags: mode 2 tests every
 box like the reference, flags equal except <= 1e-5 of the rays; mode 3 also skips boxes that start
-beyond the ray's t_max, which can only turn "occluded" into "free", for at most 2e-3 of a scene's
-shadow rays (an occluder within rounding of t_max, see pt_set_trace_mode).  Rendered film of one
-sample within |d| <= 1e-4 + 1e-3 |ref| of the oracle's film on >= 99.8 % of the pixels in mode 2 (measured:
-the same shares as mode 0, 0.9994 .. 1.0) and >= 99.5 % in mode 3 (measured 0.9964 .. 1.0; the lost
-occluders brighten a few pixels); profiles/parity_report.json."""
+beyond t_max * (1 + 2^-12), which could only turn "occluded" into "free" (an occluder within rounding of
+t_max, see pt_set_trace_mode): the same bar, <= 1e-5 of the rays.  Rendered film of one
+sample within |d| <= 1e-4 + 1e-3 |ref| of the oracle's film on >= 99.8 % of the pixels in both modes
+(measured: the same shares as mode 0, 0.9994 .. 1.0); profiles/parity_report.json."""
 import numpy as np
 import pytest
 
@@ -71,7 +70,7 @@ def test_wide_closest_and_any_hit_on_incoherent_rays(pt, ora, wide_ctx, devbuf, 
     wide_ctx.synchronize()
     occ3 = occ_d.download(np.uint8, n)
     assert not ((occ3 == 1) & (ref_occ == 0)).any()
-    assert (occ3 != ref_occ).sum() <= int(n * 2e-3)
+    assert (occ3 != ref_occ).sum() <= int(n * 1e-5)
 
 
 @pytest.mark.parametrize("name", ["teapot", "cornell", "helmet", "party_armadillo"])
@@ -98,17 +97,23 @@ def test_wide_on_the_scenes_own_bounce_and_shadow_rays(pt, ora, wide_ctx, devbuf
         total += n
         differ += int(ids.sum())
     assert total > 10000 and differ <= max(1, int(total * 1e-5)), (differ, total)
-    sh_total = sh_differ = 0
+    sh_total = sh_differ = sh_differ3 = 0
     for bounce in (0, 1):
         n = wide_ctx.capture_shadow_rays(w, h, 0, bounce, buf.ptr, w * h)
         if n == 0:
             continue
         rays = buf.download(pt.abi.RAY, n)
         occ = wide_ctx.trace_any_host(rays)
+        wide_ctx.set_trace_mode(3)
+        occ3 = wide_ctx.trace_any_host(rays)
+        wide_ctx.set_trace_mode(2)
         ref_occ = ora.trace_any(desc, rays, nthreads=8)
         sh_total += n
         sh_differ += int((occ != ref_occ).sum())
+        sh_differ3 += int((occ3 != ref_occ).sum())
+        assert not ((occ3 == 1) & (ref_occ == 0)).any()
     assert sh_total > 1000 and sh_differ <= max(1, int(sh_total * 1e-5)), (sh_differ, sh_total)
+    assert sh_differ3 <= max(1, int(sh_total * 1e-5)), (sh_differ3, sh_total)
 
 
 @pytest.mark.parametrize("mode", [2, 3])
@@ -130,7 +135,7 @@ def test_wide_one_sample_film_matches_oracle(pt, ora, gpu_ctx, scene_factory, ti
     ref, _ = ora.render(desc, w, h, 0, nthreads=8)
     assert np.isfinite(film).all() and ref.mean() > 1e-3
     close = (np.abs(film - ref) <= 1e-4 + 1e-3 * np.abs(ref)).all(axis=2)
-    assert close.mean() >= (0.998 if mode == 2 else 0.995), f"{name} mode {mode}: only {close.mean():.4f} of the pixels agree"
+    assert close.mean() >= 0.998, f"{name} mode {mode}: only {close.mean():.4f} of the pixels agree"
     assert st.paths == w * h and st.nan_pixels == 0 and st.stack_drops == 0
 
 

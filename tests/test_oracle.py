@@ -3,6 +3,8 @@ compiled in this image (parity unpinned), so the oracle is checked against what 
 independently: closed-form intersections, integer-exact PCG values computed in Python, the
 brute-force all-triangles search (the reference's own cross-check), structural BVH invariants
 and alias-table reconstruction of the input distribution."""
+import os
+
 import numpy as np
 import pytest
 
@@ -413,3 +415,18 @@ def test_texture_filter_options(pt, ora):
         assert np.array_equal(ora.sample_texture3(desc, plain, u, v), base)  # untagged images are never decoded
     finally:
         ora.set_texture_filter(0)
+
+
+def test_any_hit_with_negative_recomputed_distance_counts_as_free(pt, ora, scene_factory):
+    """A shadow ray of the helmet scene (bounce 1, captured on the GPU) whose origin touches a triangle: the
+    triangle test accepts it at t = 6.5e-6, the distance recomputed in world space comes out negative, and the
+    reference's searches then report no hit at all (kernel/intersection.h:139-149, :229-232), for the any-hit
+    query and for the closest-hit query alike, although brute force over the triangles finds the hit."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "any_hit_negative_distance.npz"))
+    hs = scene_factory(str(g["scene"]), int(g["width"]), int(g["height"]), 8)
+    desc = hs.desc()
+    rays = g["rays"].astype(pt.abi.RAY)
+    assert list(ora.trace_any(desc, rays)) == [0]
+    assert ora.trace_closest(desc, rays)["inst"][0] == -1
+    brute = ora.trace_naive(desc, rays)
+    assert brute["inst"][0] >= 0 and 0 < brute["t"][0] < 1e-5
