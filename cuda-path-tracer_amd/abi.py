@@ -125,7 +125,7 @@ class IntegratorState(C.Structure):
 class OffscreenOptions(C.Structure):
     """pth_offscreen_options."""
     _fields_ = [("iterations", C.c_uint32), ("batch", C.c_uint32), ("save_every", C.c_uint32), ("resume", C.c_int32),
-                ("output_prefix", C.c_char_p), ("checkpoint_path", C.c_char_p)]
+                ("output_prefix", C.c_char_p), ("checkpoint_path", C.c_char_p), ("window", C.c_int32 * 4)]
 
 
 class OffscreenResult(C.Structure):

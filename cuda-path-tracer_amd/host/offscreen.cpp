@@ -83,6 +83,7 @@ void RenderOffscreen(pt_ctx *ctx, Scene &scene, const pth_offscreen_options &opt
     Check(ctx, pt_scene_upload(ctx, &scene.GetDeviceScene()), "pt_scene_upload");
     Check(ctx, pt_integrator_init(ctx, width, height), "pt_integrator_init");
     Check(ctx, pt_integrator_reset(ctx, width, height), "pt_integrator_reset");
+    Check(ctx, pt_set_render_window(ctx, opt.window[0], opt.window[1], opt.window[2], opt.window[3]), "pt_set_render_window");
 
     std::vector<float> film;
     uint32_t done = 0;

@@ -105,12 +105,12 @@ def bvh_build(positions: np.ndarray, indices: np.ndarray, geometries: np.ndarray
 
 
 def render_offscreen(ctx: "Context", scene: "HostScene", iterations: int = 0, batch: int = 0, save_every: int = 0,
-                     output_prefix: str = None, checkpoint_path: str = None, resume: bool = False) -> dict:
+                     output_prefix: str = None, checkpoint_path: str = None, resume: bool = False, window=(0, 0, 0, 0)) -> dict:
     """Application::Run's offscreen branch (application.cpp:58-76): progressive PNGs, film checkpoint, resume."""
     lib = abi.load_library()
     opt = abi.OffscreenOptions(iterations, batch, save_every, int(resume),
                                output_prefix.encode() if output_prefix else None,
-                               checkpoint_path.encode() if checkpoint_path else None)
+                               checkpoint_path.encode() if checkpoint_path else None, (C.c_int32 * 4)(*window))
     res = abi.OffscreenResult()
     _host_check(lib.pth_render_offscreen(ctx.handle, scene.handle, C.byref(opt), C.byref(res)))
     return {"first_iteration": res.first_iteration, "iterations_done": res.iterations_done,

@@ -114,6 +114,8 @@ typedef struct pth_offscreen_options {
     int32_t resume;
     const char *output_prefix;    /* NULL = no PNG output */
     const char *checkpoint_path;  /* NULL = no checkpoint */
+    int32_t window[4];            /* x0, y0, w, h of the pixels to render (pt_set_render_window); all 0 = the whole frame.
+                                     Pixels outside stay zero in the film: one rank's part of an image-tile sharded job. */
 } pth_offscreen_options;
 typedef struct pth_offscreen_result {
     uint32_t first_iteration;  /* where rendering started (non-zero after a resume) */
