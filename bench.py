@@ -10,8 +10,10 @@ resident in HBM before the timed region starts.  With N ranks every rank traces 
 shards iterations over ranks (rank r renders r, r+N, ...) and ends with one RCCL reduce of the
 fp32 film to rank 0, inside the timed region.
 
-`value` is the reference-exact traversal (trace mode 0).  The 4-wide traversal (trace mode 2) is
-timed on the same batch and reported beside it together with its id mismatches against mode 0.
+Two traversals are timed on the same batch: trace mode 0 (reference-exact: ids, t, u, v bit-equal to the
+CPU oracle) and trace mode 2 (4-wide nodes; ids may differ at exact ties).  `value` is the faster of the
+modes that meet the parity bar in this very run (ids differing from mode 0 on <= 1e-5 of the rays, bit-equal
+t where the ids agree); `config.trace_mode` says which, `trace_modes` holds both.
 
 Prints ONE JSON line on rank 0.
 """
@@ -174,18 +176,23 @@ def main():
         return pt.sharding.max_over_ranks(dt, coll_dev), st.ms_closest / max(1, st.n_closest), int(st.n_closest)
 
     total_rays = total_over_ranks(n_rays)
-    wide_elapsed, wide_kernel_ms, _ = closest_leg(2)
+    wide_elapsed, wide_kernel_ms, wide_launches = closest_leg(2)
     hits_wide = hits.clone()
-    elapsed, kernel_ms, launches = closest_leg(0)
-    mrays = total_rays * args.steps / elapsed / 1e6
+    exact_elapsed, exact_kernel_ms, exact_launches = closest_leg(0)
     a, b = hits.view(torch.int32).view(-1, 8), hits_wide.view(torch.int32).view(-1, 8)
     ids_differ = int(((a[:, 3] != b[:, 3]) | (a[:, 4] != b[:, 4])).sum().item())
     t_differ_same_id = int((((a[:, 3] == b[:, 3]) & (a[:, 4] == b[:, 4])) & (a[:, 0] != b[:, 0])).sum().item())
     del hits_wide
-    modes = {"0": {"mrays_per_s": mrays, "kernel_ms": kernel_ms, "parity": "reference-exact (ids, t, u, v bit-equal to the oracle in the GPU tests)"},
+    wide_meets_bar = total_over_ranks(ids_differ) <= 1e-5 * total_rays and total_over_ranks(t_differ_same_id) == 0
+    modes = {"0": {"mrays_per_s": total_rays * args.steps / exact_elapsed / 1e6, "kernel_ms": exact_kernel_ms,
+                   "parity": "reference-exact (ids, t, u, v bit-equal to the oracle in the GPU tests)"},
              "2": {"mrays_per_s": total_rays * args.steps / wide_elapsed / 1e6, "kernel_ms": wide_kernel_ms,
                    "ids_differing_from_mode_0": ids_differ, "ids_differing_frac": ids_differ / n_rays,
-                   "t_bits_differing_where_ids_agree": t_differ_same_id, "parity": "meets the bar when ids_differing_frac <= 1e-5"}}
+                   "t_bits_differing_where_ids_agree": t_differ_same_id, "meets_parity_bar": bool(wide_meets_bar),
+                   "parity": "meets the bar when ids_differing_frac <= 1e-5 and no t differs where the ids agree"}}
+    value_mode = 2 if wide_meets_bar and wide_elapsed < exact_elapsed else 0
+    elapsed, kernel_ms, launches = (wide_elapsed, wide_kernel_ms, wide_launches) if value_mode == 2 else (exact_elapsed, exact_kernel_ms, exact_launches)
+    mrays = total_rays * args.steps / elapsed / 1e6
 
     # ---- leg 2: spp/s of the full path tracer, iterations strided over ranks + film reduce
     spp = None
@@ -327,7 +334,7 @@ def main():
     binding = None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            rec = json.load(f)["k_trace_closest"]
+            rec = json.load(f)["k_trace_closest_wide" if value_mode == 2 else "k_trace_closest"]
         if abs(rec["rays"] - n_rays) <= 0.01 * n_rays and args.rays == "captured":
             traffic = rec["traffic_bytes"]
             binding = rec.get("binding")
@@ -340,10 +347,10 @@ def main():
             "metric": f"Mrays/s incoherent closest-hit ({args.scene}, {W}x{H} {args.rays} bounce rays)", "value": mrays, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "rays_per_rank": n_rays, "scene": args.scene, "resolution": [W, H], "max_depth": depth, "trace_mode": 0,
+            "config": {"workload": workload, "rays_per_rank": n_rays, "scene": args.scene, "resolution": [W, H], "max_depth": depth, "trace_mode": value_mode,
                        "parallelism": f"rays sharded over {world} rank(s), scene replicated"},
             "roofline": {"bound": "hbm", "nominal": True, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_trace_closest", "kernel_ms": kernel_ms, "launches": launches,
+                         "traffic": traffic, "kernel": "k_trace_closest<false, true>" if value_mode == 2 else "k_trace_closest<false, false>", "kernel_ms": kernel_ms, "launches": launches,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "visits_per_ray": {"interior": csum[0] / n_rays, "tlas_leaves": csum[1] / n_rays, "triangles": csum[2] / n_rays},
                          "hbm_streamed": split_line(kernel_ms, 48.0 * n_rays, bytes_per_launch - 48.0 * n_rays),

@@ -126,8 +126,11 @@ struct ClosestIO {
     PTD void finish() const {}
 };
 
+#ifndef PT_QUERY_WAVES_PER_SIMD
+#define PT_QUERY_WAVES_PER_SIMD 4  // the 4-wide variants would otherwise take 134 registers: three waves per SIMD, 15 % slower
+#endif
 template <bool COUNT, bool WIDE = false>
-__global__ __launch_bounds__(64) void k_trace_closest(DScene S, const pt_ray *rays, uint32_t n, pt_hit *hits, uint32_t *cursors, uint32_t cursor_count,
+__global__ __launch_bounds__(64, PT_QUERY_WAVES_PER_SIMD) void k_trace_closest(DScene S, const pt_ray *rays, uint32_t n, pt_hit *hits, uint32_t *cursors, uint32_t cursor_count,
                                                       uint2 *spill, uint32_t spill_stride, DevStats *stats, TraceCounters *counters) {
     LaneEvents ev;
     ClosestIO<COUNT> io{S, rays, hits, counters};
@@ -383,8 +386,11 @@ struct ExtendIO {
     }
 };
 
+#ifndef PT_EXTEND_WAVES_PER_SIMD
+#define PT_EXTEND_WAVES_PER_SIMD 4
+#endif
 template <bool WIDE = false>
-__global__ __launch_bounds__(64) void k_extend(DScene S, PathState P, BounceCounters *cnt, int bounce, int width, int height, uint2 *spill,
+__global__ __launch_bounds__(64, PT_EXTEND_WAVES_PER_SIMD) void k_extend(DScene S, PathState P, BounceCounters *cnt, int bounce, int width, int height, uint2 *spill,
                                                uint32_t spill_stride, DevStats *stats) {
     BounceCounters *bc = cnt + bounce;
     LaneEvents ev;
@@ -769,8 +775,11 @@ struct ShadowIO {
     PTD void finish() const {}
 };
 
+#ifndef PT_SHADOW_WAVES_PER_SIMD
+#define PT_SHADOW_WAVES_PER_SIMD 4
+#endif
 template <bool WIDE = false>
-__global__ __launch_bounds__(64) void k_shadow(DScene S, PathState P, BounceCounters *cnt, int bounce, uint2 *spill,
+__global__ __launch_bounds__(64, PT_SHADOW_WAVES_PER_SIMD) void k_shadow(DScene S, PathState P, BounceCounters *cnt, int bounce, uint2 *spill,
                                                uint32_t spill_stride, DevStats *stats) {
     BounceCounters *bc = cnt + bounce;
     LaneEvents ev;

@@ -30,10 +30,11 @@ def short(name):
 
 
 EXACT = "k_trace_closest<false, false>"
+WIDE = "k_trace_closest<false, true>"
 
 
-def sq_binding(base):
-    """What limits the closest-hit kernel, from the shader-engine counter passes of tools/profile_sq.sh."""
+def sq_binding(base, kernel=EXACT):
+    """What limits a closest-hit kernel, from the shader-engine counter passes of tools/profile_sq.sh."""
     vals = {}
     for name in "abc":
         f = newest(os.path.join(base, name, "*", "*counter_collection.csv"))
@@ -41,7 +42,7 @@ def sq_binding(base):
             continue
         acc = defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if short(r["Kernel_Name"]) != EXACT:
+            if short(r["Kernel_Name"]) != kernel:
                 continue
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
             vals["vgpr_count_field"] = r.get("VGPR_Count")
@@ -63,8 +64,10 @@ def sq_binding(base):
     if vals.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
         out["tcp_accesses_per_cycle_per_cu"] = vals["TCP_TOTAL_CACHE_ACCESSES_sum"] / (256.0 * kernel_cycles)
         out["l1_hit_frac"] = 1.0 - vals.get("TCP_TCC_READ_REQ_sum", 0.0) / vals["TCP_TOTAL_CACHE_ACCESSES_sum"]
-    out["resource"] = ("VALU issue: the vector pipes are busy for valu_busy_frac of the launch at lane_utilisation of their lanes, "
-                       "4 waves per SIMD (116 VGPRs, 10 KB of LDS per wave); HBM carries a few per cent of the algorithmic bytes")
+    out["resource"] = ("VALU issue: valu_busy_frac is every vector instruction priced at 4 cycles of its SIMD over the launch (measured per "
+                       "instruction class, profiles/r2_ubench_*.txt: 2.7 cycles for fp32 add / mul / fma, 4 to 4.7 for min / max / compare / select / "
+                       "integer, so the true share lies a little below), at lane_utilisation of the lanes, 4 waves per SIMD (registers and 10 KB of "
+                       "LDS per wave both allow no more); HBM carries a few per cent of the algorithmic bytes")
     out["source"] = "tools/profile_sq.sh: rocprofv3 --pmc, three separate passes over bench.py --steps 3 --spp-steps 0"
     return out
 
@@ -93,22 +96,27 @@ def main():
     line = [ln for ln in open(os.path.join(PROF, "bench_fetch.log")) if ln.startswith("{")][-1]
     bench = json.loads(line)
     rays = bench["config"]["rays_per_rank"]
-    fetch_kb = means[("fetch", EXACT, "FETCH_SIZE")]
-    write_kb = means[("write", EXACT, "WRITE_SIZE")]
     s32, g64 = means[("calib_fetch", "stream32", "FETCH_SIZE")], means[("calib_fetch", "gather64", "FETCH_SIZE")]
     w32 = means[("calib_write", "stream32", "WRITE_SIZE")]
-    traffic = fetch_kb * 1024 + rays * 32 * 0.5 + write_kb * 1024
-    json.dump({"k_trace_closest": {
-        "workload": bench["config"]["workload"], "rays": rays, "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
-        "correction": f"FETCH_SIZE counts a wide coalesced stream at 1/2 (pmc_calib stream32: {s32:.0f} KB for 536.9 MB) and random 64-byte "
-                      f"records exactly (gather64: {g64:.0f} KB for 1073.7 MB); the 32-byte ray stream (rays*32 B) is therefore added once more "
-                      f"at half weight; WRITE_SIZE is exact for 32-byte records ({w32:.0f} KB for 536.9 MB)",
-        "traffic_bytes": traffic,
-        "l2_hit_frac": (means[("l2", EXACT, "TCC_HIT_sum")] / (means[("l2", EXACT, "TCC_HIT_sum")] + means[("l2", EXACT, "TCC_MISS_sum")])
-                        if ("l2", EXACT, "TCC_HIT_sum") in means else None),
-        "binding": sq_binding(os.path.join(ROOT, "gpurun_out", "sq")),
-        "source": f"profiles/{tag}_pmc_per_kernel.csv (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of bench.py --steps 3)"}},
-        open(os.path.join(OUT, "traffic.json"), "w"), indent=1)
+    records = {}
+    for key, kernel in (("k_trace_closest", EXACT), ("k_trace_closest_wide", WIDE)):
+        if ("fetch", kernel, "FETCH_SIZE") not in means:
+            continue
+        fetch_kb = means[("fetch", kernel, "FETCH_SIZE")]
+        write_kb = means[("write", kernel, "WRITE_SIZE")]
+        traffic = fetch_kb * 1024 + rays * 32 * 0.5 + write_kb * 1024
+        records[key] = {
+            "kernel": kernel, "workload": bench["config"]["workload"], "rays": rays, "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
+            "correction": f"FETCH_SIZE counts a wide coalesced stream at 1/2 (pmc_calib stream32: {s32:.0f} KB for 536.9 MB) and random 64-byte "
+                          f"records exactly (gather64: {g64:.0f} KB for 1073.7 MB); the 32-byte ray stream (rays*32 B) is therefore added once more "
+                          f"at half weight; WRITE_SIZE is exact for 32-byte records ({w32:.0f} KB for 536.9 MB)",
+            "traffic_bytes": traffic,
+            "l2_hit_frac": (means[("l2", kernel, "TCC_HIT_sum")] / (means[("l2", kernel, "TCC_HIT_sum")] + means[("l2", kernel, "TCC_MISS_sum")])
+                            if ("l2", kernel, "TCC_HIT_sum") in means else None),
+            "binding": sq_binding(os.path.join(ROOT, "gpurun_out", "sq"), kernel),
+            "source": f"profiles/{tag}_pmc_per_kernel.csv (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of bench.py --steps 3)"}
+    json.dump(records, open(os.path.join(OUT, "traffic.json"), "w"), indent=1)
+    traffic = records["k_trace_closest"]["traffic_bytes"]
     print("traffic bytes per launch", traffic)
     for r in rows:
         if r[1] == EXACT:
