@@ -13,7 +13,10 @@ fp32 film to rank 0, inside the timed region.
 Two traversals are timed on the same batch: trace mode 0 (reference-exact: ids, t, u, v bit-equal to the
 CPU oracle) and trace mode 2 (4-wide nodes; ids may differ at exact ties).  `value` is the faster of the
 modes that meet the parity bar in this very run (ids differing from mode 0 on <= 1e-5 of the rays, bit-equal
-t where the ids agree); `config.trace_mode` says which, `trace_modes` holds both.
+t where the ids agree); `config.trace_mode` says which, `trace_modes` holds both.  The spp/s leg does the same over
+all four trace modes: every mode renders the same iterations, and the fastest mode whose film equals mode 0's within
+RMSE / mean <= 1e-3 (and differs at all on <= 1e-3 of the pixels) is the one reported (`spp.trace_mode`), with every
+mode's rate and film difference beside it.
 
 Prints ONE JSON line on rank 0.
 """
@@ -205,6 +208,8 @@ def main():
             ctx.render_batch(W, H, w_pass * B, B)
         ctx.synchronize()
 
+        mode_film = torch.empty(H * W * 3, dtype=torch.float32, device=dev)
+
         def render_leg(mode, reduce):
             ctx.set_trace_mode(mode)
             ctx.reset_stats()
@@ -218,11 +223,34 @@ def main():
             ctx.set_trace_mode(0)
             return dt
 
-        spp_elapsed = render_leg(0, True)
+        # every mode renders the same iterations; a mode other than 0 may stand for the job when its film equals
+        # mode 0's (the reference-exact one, itself held against the oracle's film in the GPU tests) within the
+        # stated bound: RMSE over the film mean <= 1e-3 and at most 1e-3 of the pixels different at all
+        legs = {}
+        exact_film = None
+        for m in (1, 2, 3, 0):  # mode 0 last: its stats and film are what the rest of the line refers to
+            dt = render_leg(m, False)
+            ctx.film_copy_to_device(mode_film.data_ptr())
+            legs[m] = {"seconds": dt, "film": mode_film.clone() if m != 0 else None}
+            if m == 0:
+                exact_film = mode_film
+        spp_by_mode, film_vs_exact = {}, {}
+        mean = float(exact_film.mean().item())
+        for m, leg in legs.items():
+            spp_by_mode[str(m)] = args.spp_steps * world / leg["seconds"]
+            if m != 0:
+                d = leg["film"] - exact_film
+                film_vs_exact[str(m)] = {"rmse_over_mean": float(d.pow(2).mean().sqrt().item()) / max(mean, 1e-30),
+                                         "pixels_differing": float((d.view(-1, 3) != 0).any(dim=1).float().mean().item())}
+                leg["film"] = None
+        ok_modes = [0] + [m for m in (1, 2, 3) if film_vs_exact[str(m)]["rmse_over_mean"] <= 1e-3 and film_vs_exact[str(m)]["pixels_differing"] <= 1e-3]
+        spp_mode = max(ok_modes, key=lambda m: spp_by_mode[str(m)])
         st2 = ctx.stats()
-        # the other trace modes, reported beside the reference-exact figure, never as `value`
-        other = {str(m): args.spp_steps * world / render_leg(m, False) for m in (1, 2, 3)}
+        # the reported job, with the film reduce inside the timed region
+        spp_elapsed = render_leg(spp_mode, True)
         spp_rate = args.spp_steps * world / spp_elapsed
+        spp_by_mode[str(spp_mode)] = spp_rate
+        del mode_film, exact_film
 
         # Algorithmic bytes of one sample per pixel (iteration 0 of this scene): per bounce the extension
         # and shadow rays are captured and their visits counted in the reference's binary BVH.
@@ -251,17 +279,19 @@ def main():
         # kernel times of one pass, passes one after the other on one stream (HIP events around every launch)
         ctx.integrator_reset(W, H)
         ctx.reset_stats()
+        ctx.set_trace_mode(spp_mode)
         ctx.set_profiling(True)
         ctx.render_batch(W, H, 0, B)
         ctx.synchronize()
         ctx.set_profiling(False)
+        ctx.set_trace_mode(0)
         stp = ctx.stats()
         per_gpu_rate = spp_rate / world
         spp = {"spp_per_s": spp_rate, "ms_per_spp": spp_elapsed * 1e3 / (args.spp_steps * world),
                "mpaths_per_s": spp_rate * W * H / 1e6,
                "rays_last_pass": {"closest": int(st2.closest_rays), "shadow": int(st2.shadow_rays)},
                "iterations": args.spp_steps * world, "samples_in_flight": B, "shard": args.shard,
-               "spp_per_s_by_trace_mode": {"0": spp_rate, **other},
+               "trace_mode": spp_mode, "spp_per_s_by_trace_mode": spp_by_mode, "film_vs_trace_mode_0": film_vs_exact,
                "film_reduce": (("rccl" if backend == "nccl" else backend + " (rehearsal, staged through the host)") + " reduce(sum) to rank 0") if distributed else "none",
                "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                             "A_sample_bytes_per_pixel": sample_bytes / P, "A_sample_streamed_bytes_per_pixel": streamed_bytes / P,
