@@ -19,11 +19,13 @@
 #include "traverse.h"
 
 // Trace modes 1 and 3 let any-hit searches skip boxes that start beyond t_max * (1 + margin).  The
-// margin is there for the reference's shadow rays: they start 1e-5 along the ray and end at distance - 1e-5
-// (path_trace.cu:314-318), so the sampled light's own surface lies at t_max to within rounding, and whether
-// its triangle counts as an occluder is decided by the last bits of the triangle test.  A box test with a
-// different rounding must not pre-empt that decision.  Measured on 17.6 M captured shadow rays of five
-// scenes: 12 800 flags differ from the reference's without a margin, 9 500 with 2^-16, none with 2^-12.
+// margin is there for the reference's shadow rays: they end 1e-4 before the sampled point of the light
+// (path_trace.cu:221-227).  When such a ray grazes a flat light, the distance the triangle test computes to
+// the light's own triangle is ill-conditioned (its error grows with 1 / sin of the grazing angle, 5e-3 at
+// 0.006 degrees) and can land before t_max: the reference then counts the light as its own occluder.  The
+// light's flat box is computed with another rounding and can land behind t_max, so a plain t_max cull
+// pre-empts that decision.  Measured on 17.6 M captured shadow rays of five scenes: 12 800 flags differ from
+// the reference's without a margin, 9 500 with 2^-16, none with 2^-12.
 #ifndef PT_ANY_CULL_MARGIN
 #define PT_ANY_CULL_MARGIN 2.44140625e-4f
 #endif

@@ -470,7 +470,7 @@ int pt_capture_bounce_rays(pt_ctx *ctx, int width, int height, int iteration, in
                            pt_ray *rays_device, size_t capacity, size_t *count);
 
 /* Captures the shadow rays (next-event estimation, path_trace.cu:221-243) that the shading of
- * `bounce` emits in `iteration`, with their t_max = distance - 1e-5, in queue order.          */
+ * `bounce` emits in `iteration`, with their t_max = distance - 1e-4, in queue order.          */
 int pt_capture_shadow_rays(pt_ctx *ctx, int width, int height, int iteration, int bounce,
                            pt_ray *rays_device, size_t capacity, size_t *count);
 
@@ -484,8 +484,10 @@ int pt_capture_shadow_rays(pt_ctx *ctx, int width, int height, int iteration, in
  *   does not do (kernel/intersection.h:120-121,209-210 test child boxes against FLT_MAX): fewer nodes are
  *   visited (2.5x faster shadow rays in the 20 001-instance scene).  A box test and a triangle test round
  *   differently, so in principle "occluded" can turn into "free" for a triangle within rounding of t_max;
- *   the margin keeps the decision with the triangle test where the reference's own shadow rays put
- *   geometry exactly there (the sampled light, path_trace.cu:314-318).  Measured against the CPU oracle
+ *   the margin keeps the decision with the triangle test where the reference's own shadow rays produce
+ *   that case (a ray grazing the flat light it was aimed at: the ill-conditioned distance to the light's own
+ *   triangle can fall before t_max = distance - 1e-4, path_trace.cu:221-227, and the reference then counts
+ *   the light as its own occluder).  Measured against the CPU oracle
  *   on 2.1 M captured shadow rays of three scenes and against mode 0 on 17.6 M of five: no flag differs.
  * Bit 1 (modes 2, 3): the trees are walked as 4-wide nodes (128 bytes: the reference's own fp32 boxes
  *   of four children, tested with the reference's arithmetic), the top level is rebuilt top down over

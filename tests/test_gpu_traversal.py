@@ -108,7 +108,7 @@ def test_any_hit_matches_oracle(pt, ora, gpu_ctx, devbuf, scene_factory, tiny_sc
 @pytest.mark.parametrize("name", ["teapot", "helmet", "cornell", "pbr_ior", "instancing_stress"])
 def test_any_hit_on_captured_shadow_rays(pt, ora, gpu_ctx, devbuf, scene_factory, name):
     """The next-event-estimation rays the shading really emits (t_max = distance to the light sample
-    - 1e-5): the occlusion flags equal the oracle's, and both outcomes occur."""
+    - 1e-4): the occlusion flags equal the oracle's, and both outcomes occur."""
     w, h = 96, 96
     hs = scene_factory(name, w, h, 6)
     desc = _upload_scene(gpu_ctx, hs)
