@@ -300,16 +300,25 @@ def main():
                             "scene_gather_achieved": (sample_bytes - streamed_bytes) * per_gpu_rate / 1e9, "scene_gather_ceiling": GATHER_CEILING_GBS,
                             "scene_gather_frac": (sample_bytes - streamed_bytes) * per_gpu_rate / 1e9 / GATHER_CEILING_GBS,
                             "kernels_one_pass_serial": {
-                                "k_extend": split_line(stp.ms_closest, ext_streamed * B, (ext_bytes - ext_streamed) * B),
-                                "k_shade": split_line(stp.ms_shade, state_bytes * B, 0.0),
-                                "k_shadow": split_line(stp.ms_any, sh_streamed * B, (sh_bytes - sh_streamed) * B),
-                                "k_generate": split_line(stp.ms_generate, 88.0 * P * B, 0.0),
+                                # bytes each kernel of THIS layout moves per unit (SoA path state, csrc/kernels.h), so that no line can
+                                # exceed what the kernel really streams: extend = queue entry + ray (36 B) in, hit record + class entry
+                                # (20 B) out per hit; shade = 76 B in (queue entry, ray, throughput, hit, sampler) and 76 B out (next
+                                # ray, throughput, sampler, last position, queue entry) per shaded path + 52 B per shadow ray emitted;
+                                # shadow = 36 B in + 48 B (contribution, accumulator read-modify-write) per unoccluded ray, taken for
+                                # all; generate = 72 B per path; film = 16 B per sample + 24 B per pixel
+                                "k_extend": split_line(stp.ms_closest, 36.0 * stp.closest_rays + 20.0 * stp.shaded_paths, (ext_bytes - ext_streamed) * B),
+                                "k_shade": split_line(stp.ms_shade, 152.0 * stp.shaded_paths + 52.0 * stp.shadow_rays, 0.0),
+                                "k_shadow": split_line(stp.ms_any, 84.0 * stp.shadow_rays, (sh_bytes - sh_streamed) * B),
+                                "k_generate": split_line(stp.ms_generate, 72.0 * P * B, 0.0),
                                 "k_film": split_line(stp.ms_film, (16.0 * B + 24.0) * P, 0.0)},
+                            "rays_serial_pass": {"closest": int(stp.closest_rays), "shadow": int(stp.shadow_rays), "shaded_paths": int(stp.shaded_paths)},
                             "note": "per pixel and sample: 88 B generate + per extension ray A_ray + per shadow ray A_ray(any, 4 B out) + 2 x 184 B of path state "
                                     "per bounce + 24 B film, visits counted in the reference's binary BVH on iteration 0.  `achieved` / `frac` take the bytes that "
                                     "have to stream through HBM (rays, hit records, path state, film); the node / triangle / instance bytes are L2 / MALL "
-                                    "resident and are held against the measured dependent-gather ceiling instead.  Kernel lines: one pass of "
-                                    f"{B} samples with its launches serialised on one stream"}}
+                                    "resident and are held against the measured dependent-gather ceiling instead.  A_sample follows the reference's record sizes "
+                                    f"(184 B of path state read and written per bounce).  Kernel lines: one pass of {B} samples with its launches serialised on "
+                                    "one stream, streamed bytes counted from this layout's own records (k_shade gathers its vertex, light and texture records "
+                                    "from L2-resident tables on top of that and is bound by the latency of those dependent gathers, not by its streamed bytes)"}}
 
     # ---- leg 3: CPU baseline (rank 0, N == 1 only): the oracle's traversal on a bounded sample
     cpu = None

@@ -113,7 +113,7 @@ class Stats(C.Structure):
         ("ms_closest", C.c_double), ("ms_any", C.c_double), ("ms_generate", C.c_double), ("ms_shade", C.c_double),
         ("ms_film", C.c_double),
         ("n_closest", C.c_uint32), ("n_any", C.c_uint32), ("n_generate", C.c_uint32), ("n_shade", C.c_uint32),
-        ("n_film", C.c_uint32)]
+        ("n_film", C.c_uint32), ("_reserved", C.c_uint32), ("shaded_paths", C.c_uint64)]
 
 
 class IntegratorState(C.Structure):

@@ -601,6 +601,7 @@ int pt_get_stats(pt_ctx *ctx, pt_stats *out) {
         HIP_TRY(ctx, hipMemcpy(bc.data(), last_counters, bc.size() * sizeof(BounceCounters), hipMemcpyDeviceToHost));
         ctx->stats.closest_rays = 0;
         ctx->stats.shadow_rays = 0;
+        ctx->stats.shaded_paths = 0;
         ctx->stats.bounces_run = 0;
         std::memset(ctx->stats.queue_sizes, 0, sizeof(ctx->stats.queue_sizes));
         // bounce 0 streams all path slots (8x8-tile padded); its real ray count is one per pixel
@@ -608,6 +609,7 @@ int pt_get_stats(pt_ctx *ctx, pt_stats *out) {
         for (int b = 0; b < ctx->last_render_bounces; ++b) {
             ctx->stats.closest_rays += bc[b].ext_count;
             ctx->stats.shadow_rays += bc[b].shadow_count;
+            for (int k = 0; k < kNumClasses; ++k) ctx->stats.shaded_paths += bc[b].class_count[k];
             if (bc[b].ext_count) ctx->stats.bounces_run = uint32_t(b + 1);
             if (b < PT_MAX_TRACKED_BOUNCES) ctx->stats.queue_sizes[b] = bc[b].ext_count;
         }

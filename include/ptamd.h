@@ -232,6 +232,8 @@ typedef struct pt_stats {
     uint32_t queue_sizes[PT_MAX_TRACKED_BOUNCES]; /* extension queue per bounce */
     double ms_closest, ms_any, ms_generate, ms_shade, ms_film; /* summed ms   */
     uint32_t n_closest, n_any, n_generate, n_shade, n_film;    /* launches    */
+    uint32_t _reserved;
+    uint64_t shaded_paths;   /* closest hits of the last pt_render: paths that entered a material / emissive queue, all bounces */
 } pt_stats;
 
 /* The record sizes the reference's host vectors have; a reinterpret_cast of

@@ -18,8 +18,9 @@ ctx.integrator_init(W, H)
 dev = torch.device("cuda", 0)
 tmp = torch.empty(W * H * 8, dtype=torch.float32, device=dev)
 chunks = []
+# PT_BOUNCES=0 profiles the camera rays (coherent), the default 1,2,3 the bench's incoherent batch
 for it in range(2):
-    for b in (1, 2, 3):
+    for b in [int(x) for x in os.environ.get("PT_BOUNCES", "1,2,3").split(",")]:
         n = ctx.capture_bounce_rays(W, H, it, b, tmp.data_ptr(), W * H)
         chunks.append(tmp[: n * 8].clone())
 rays = torch.cat(chunks)
