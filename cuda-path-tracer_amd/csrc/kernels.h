@@ -386,9 +386,6 @@ struct ExtendIO {
     }
 };
 
-#ifndef PT_CAMERA_REFILL_MIN
-#define PT_CAMERA_REFILL_MIN 64  // camera rays: a wave takes a whole 8x8 pixel tile at a time (trace_stream)
-#endif
 #ifndef PT_EXTEND_WAVES_PER_SIMD
 #define PT_EXTEND_WAVES_PER_SIMD 4
 #endif
@@ -403,8 +400,7 @@ __global__ __launch_bounds__(64, PT_EXTEND_WAVES_PER_SIMD) void k_extend(DScene 
     constexpr int kDepth = WIDE ? kRenderLdsDepthWide : kRenderLdsDepth;
     __shared__ unsigned long long lds[wave_lds_entries<kDepth>()];
     const auto stk = make_lane_stack<kDepth>(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
-    trace_stream<MODE_CLOSEST, false, WIDE>(S, io, bc->ext_count, make_feed(&bc->cur_extend, 1u, bc->ext_count), stk, ev,
-                                            bounce == 0 ? PT_CAMERA_REFILL_MIN : kRefillMin);
+    trace_stream<MODE_CLOSEST, false, WIDE>(S, io, bc->ext_count, make_feed(&bc->cur_extend, 1u, bc->ext_count), stk, ev);
     flush_events(stats, ev);
 }
 

@@ -511,11 +511,8 @@ PTD bool fetch_rays(const WorkFeed &feed, uint32_t n, uint32_t &dry, uint32_t &b
     return true;
 }
 
-// refill_min (wave-uniform): idle lanes that trigger a refill.  Incoherent streams refill early (kRefillMin) so that
-// lanes do not sit idle behind their neighbours' long rays; a coherent stream (camera rays of one 8x8 pixel tile per
-// 64 entries) does better when the wave takes a tile at a time: its rays then walk the same nodes in the same rounds.
 template <int MODE, bool COUNT, bool WIDE = false, class IO, class STK>
-PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed, const STK &stk, LaneEvents &ev, int refill_min = kRefillMin) {
+PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed, const STK &stk, LaneEvents &ev) {
     Traversal<MODE, COUNT, STK::kDepth, WIDE> tr;
     tr.cur = kNoRef;
     tr.in_blas = false;
@@ -540,7 +537,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
     const uint32_t lane_id = threadIdx.x & 63u;
     for (;;) {
         int idle = count_lanes(!active);
-        if (idle >= refill_min || idle == kWave) {
+        if (idle >= kRefillMin || idle == kWave) {
             io.flush();
             for (;;) {
                 if (stage_next == stage_end) {  // restock
@@ -578,7 +575,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
                 stage_next = (stage_end - stage_next < wanted) ? stage_end : stage_next + wanted;
                 if (stage_next < stage_end) break;  // every idle lane was offered a ray
                 idle = count_lanes(!active);
-                if (idle < refill_min) break;
+                if (idle < kRefillMin) break;
             }
             if (exhausted && pool_next >= pool_end && stage_next == stage_end && count_lanes(!active) == kWave) break;
         }
@@ -588,7 +585,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
     for (;;) {
         const uint64_t idle_mask = __ballot(!active);
         const int idle = __popcll(idle_mask);
-        if (idle >= refill_min || idle == kWave) {
+        if (idle >= kRefillMin || idle == kWave) {
             io.flush();
             if (pool_next >= pool_end && !exhausted) {
                 if (!fetch_rays(feed, n, dry, pool_next, pool_end)) exhausted = dry >= feed.groups;
@@ -709,7 +706,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
                 tr.op_enter(S);
             }
         }
-        if (n_lvl > 0 && (n_lvl >= PT_VOTE_RARE || n_lvl == n_max || drain || (can_refill && n_lvl + idle >= refill_min))) {
+        if (n_lvl > 0 && (n_lvl >= PT_VOTE_RARE || n_lvl == n_max || drain || (can_refill && n_lvl + idle >= kRefillMin))) {
             if (w_deep) tr.deep_pop(stk);
             if (w_lvl) {
                 PT_PHASE(ev, 4);
