@@ -47,6 +47,26 @@ PTD float gmin(float a, float b) { return b < a ? b : a; }  // glm::min / std::m
 PTD float gmax(float a, float b) { return a < b ? b : a; }  // glm::max / std::max
 PTD V3 mix3(V3 a, V3 b, float t) { return a * (1.0f - t) + b * t; }
 
+// sin and cos of an azimuth phi in [0, 2*pi] (math/sampling.h:33-35, :44-56 call sinf / cosf there).  Every
+// implementation of those rounds differently in the last bit (CUDA's, glibc's, the ROCm device library's), and one
+// differing bit in a sampled direction sends a path down another branch a few bounces later.  So the azimuth
+// functions are defined here as a fixed sequence of correctly rounded fp32 operations, which a CPU can repeat bit for
+// bit: quadrant k = int(phi * 2/pi + 0.5); r = (phi - k * 1.5703125) - k * 4.8382679e-4 (pi/2 split in two parts);
+// with z = r * r: sin r = r + r * z * (S0 + z * (S1 + z * S2)), cos r = (1 - z/2) + z * z * (C0 + z * (C1 + z * C2))
+// (single-precision minimax coefficients, error below 1.2e-7 over the quadrant), then the quadrant's rotation.
+PTD void sincos_azimuth(float phi, float &sin_phi, float &cos_phi) {
+    const int k = int(phi * 0.63661977236758134f + 0.5f);
+    const float kf = float(k);
+    const float r = (phi - kf * 1.5703125f) - kf * 4.83826794897e-4f;
+    const float z = r * r;
+    const float s = r + (r * z) * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
+    const float c = (1.0f - 0.5f * z) + (z * z) * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
+    const bool swap = (k & 1) != 0;
+    const float ss = swap ? c : s, cc = swap ? s : c;
+    sin_phi = (k & 2) ? -ss : ss;
+    cos_phi = ((k + 1) & 2) ? -cc : cc;
+}
+
 // 3x4 affine part of a column-major mat4: columns c0..c3 (xyz each).
 struct M34 {
     V3 c0, c1, c2, c3;

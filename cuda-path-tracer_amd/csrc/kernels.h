@@ -238,7 +238,9 @@ __global__ void k_gen_incoherent(DScene S, pt_ray *rays, uint32_t n, uint64_t fi
     const float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
     float4 *rp = reinterpret_cast<float4 *>(rays + k);
     rp[0] = make_float4(o[0], o[1], o[2], 0.0f);
-    rp[1] = make_float4(r * cosf(phi), r * sinf(phi), z, FLT_MAX);
+    float sin_phi, cos_phi;
+    sincos_azimuth(phi, sin_phi, cos_phi);
+    rp[1] = make_float4(r * cos_phi, r * sin_phi, z, FLT_MAX);
 }
 
 // ------------------------------------------------------------ path pipeline

@@ -159,14 +159,18 @@ PTD V3 sample_cosine_hemisphere(V3 normal, float sx, float sy) {  // math/sampli
     const float z = sqrtf(sx);
     const float phi = 2 * kPi * sy;
     const float r = sqrtf(gmax(0.0f, 1.0f - z * z));
-    return to_world(mk3(r * cosf(phi), r * sinf(phi), z), normal);
+    float sin_phi, cos_phi;
+    sincos_azimuth(phi, sin_phi, cos_phi);
+    return to_world(mk3(r * cos_phi, r * sin_phi, z), normal);
 }
 PTD V3 sample_ggx(V3 normal, float roughness, float sx, float sy) {  // math/sampling.h:40-58
     const float a2 = roughness * roughness;
     const float phi = 2.0f * kPi * sx;
     const float cos_theta = sqrtf((1.0f - sy) / (1.0f + (a2 - 1.0f) * sy));
     const float sin_theta = sqrtf(gmax(0.0f, 1.0f - cos_theta * cos_theta));
-    return to_world(mk3(sin_theta * cosf(phi), sin_theta * sinf(phi), cos_theta), normal);
+    float sin_phi, cos_phi;
+    sincos_azimuth(phi, sin_phi, cos_phi);
+    return to_world(mk3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta), normal);
 }
 PTD float power_heuristic(float f, float g) { return (f * f) / (f * f + g * g); }                 // sampling.h:70-72
 PTD float luminance(V3 c) { return c.x * 0.212671f + c.y * 0.715160f + c.z * 0.072169f; }         // color.h:7-9

@@ -866,12 +866,36 @@ static inline vec3 ToWorldSpace(vec3 local, vec3 normal) {
     vec3 bitangent = normalize(cross(normal, tangent));
     return tangent * local.x + bitangent * local.y + normal * local.z;
 }
+// sinf / cosf of the azimuth (math/sampling.h:33-35, :44-56).  No two libraries round these alike in the last bit
+// (CUDA's, glibc's, the device library's), so the build under test and this restatement both use the same fixed
+// sequence of correctly rounded fp32 operations, restated here from its definition: quadrant k = int(phi * 2/pi +
+// 0.5); r = (phi - k * 1.5703125) - k * 4.8382679e-4; z = r * r; sin r = r + r z (S0 + z (S1 + z S2));
+// cos r = (1 - z / 2) + z z (C0 + z (C1 + z C2)); then the rotation by k quadrants.  tests/test_oracle.py holds it
+// against double-precision sin / cos (error below 1.5e-7).
+static inline void SinCosAzimuth(float phi, float &sin_phi, float &cos_phi) {
+    static const float S[3] = {-1.6666654611e-1f, 8.3321608736e-3f, -1.9515295891e-4f};
+    static const float C[3] = {4.166664568298827e-2f, -1.388731625493765e-3f, 2.443315711809948e-5f};
+    int k = int(phi * 0.63661977236758134f + 0.5f);
+    float kf = float(k);
+    float r = (phi - kf * 1.5703125f) - kf * 4.83826794897e-4f;
+    float z = r * r;
+    float sin_r = r + (r * z) * (S[0] + z * (S[1] + z * S[2]));
+    float cos_r = (1.0f - 0.5f * z) + (z * z) * (C[0] + z * (C[1] + z * C[2]));
+    switch (k & 3) {
+        case 0: sin_phi = sin_r; cos_phi = cos_r; break;
+        case 1: sin_phi = cos_r; cos_phi = -sin_r; break;
+        case 2: sin_phi = -sin_r; cos_phi = -cos_r; break;
+        default: sin_phi = -cos_r; cos_phi = sin_r; break;
+    }
+}
 // math/sampling.h:30-38
 static inline vec3 SampleCosineHemisphere(vec3 normal, vec2 sample) {
     float z = sqrtf(sample.x);
     float phi = 2 * PI * sample.y;
     float r = sqrtf(std::max(0.0f, 1.0f - z * z));
-    vec3 local = {r * cosf(phi), r * sinf(phi), z};
+    float sin_phi, cos_phi;
+    SinCosAzimuth(phi, sin_phi, cos_phi);
+    vec3 local = {r * cos_phi, r * sin_phi, z};
     return ToWorldSpace(local, normal);
 }
 // math/sampling.h:40-58
@@ -880,7 +904,9 @@ static inline vec3 SampleGGX(vec3 normal, float roughness, vec2 sample) {
     float phi = 2.0f * PI * sample.x;
     float cos_theta = sqrtf((1.0f - sample.y) / (1.0f + (a2 - 1.0f) * sample.y));
     float sin_theta = sqrtf(std::max(0.0f, 1.0f - cos_theta * cos_theta));
-    vec3 local = {sin_theta * cosf(phi), sin_theta * sinf(phi), cos_theta};
+    float sin_phi, cos_phi;
+    SinCosAzimuth(phi, sin_phi, cos_phi);
+    vec3 local = {sin_theta * cos_phi, sin_theta * sin_phi, cos_theta};
     return ToWorldSpace(local, normal);
 }
 // math/sampling.h:61-68
@@ -1714,6 +1740,9 @@ int ora_trace_closest(const pt_scene_desc *desc, const pt_ray *rays, size_t n, p
     }
     return 0;
 }
+void ora_sincos_azimuth(const float *phi, size_t n, float *sin_phi, float *cos_phi) {
+    for (size_t i = 0; i < n; ++i) SinCosAzimuth(phi[i], sin_phi[i], cos_phi[i]);
+}
 int ora_trace_any(const pt_scene_desc *desc, const pt_ray *rays, size_t n, uint8_t *occluded, int nthreads) {
     Scene scene = make_scene(desc);
     parallel_for(n, nthreads, [&](size_t b, size_t e, int) {
@@ -1771,7 +1800,9 @@ void ora_generate_incoherent_rays(const pt_scene_desc *desc, pt_ray *rays, size_
         float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
         rays[k].origin[0] = o[0]; rays[k].origin[1] = o[1]; rays[k].origin[2] = o[2];
         rays[k].tmin = 0.0f;
-        rays[k].direction[0] = r * cosf(phi); rays[k].direction[1] = r * sinf(phi); rays[k].direction[2] = z;
+        float sin_phi, cos_phi;
+        SinCosAzimuth(phi, sin_phi, cos_phi);
+        rays[k].direction[0] = r * cos_phi; rays[k].direction[1] = r * sin_phi; rays[k].direction[2] = z;
         rays[k].tmax = FLT_MAX;
     }
 }

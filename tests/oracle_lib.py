@@ -227,6 +227,16 @@ def set_texture_filter(options: int):
     lib().ora_set_texture_filter(int(options))
 
 
+def sincos_azimuth(phi):
+    """The fixed-sequence sin / cos both sides use for sampled azimuths (SinCosAzimuth in oracle.cpp)."""
+    p = np.ascontiguousarray(phi, np.float32)
+    s, c = np.zeros_like(p), np.zeros_like(p)
+    fn = lib().ora_sincos_azimuth
+    fn.restype = None
+    fn(abi.vptr(p), C.c_size_t(len(p)), abi.vptr(s), abi.vptr(c))
+    return s, c
+
+
 def pcg_hash(values):
     L = lib()
     return np.array([L.ora_pcg_hash(int(v)) for v in values], np.uint32)

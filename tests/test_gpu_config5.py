@@ -4,9 +4,7 @@ against the CPU oracle, through the C ABI.  20 001 instances is near the 32 767 
 16-bit TLAS child indices allow.
 
 Bars: traversal bit-equal to the oracle (ids, distances, barycentrics, visit counts); one-sample
-film parity per pixel to |d| <= 1e-4 + 1e-3 |ref| on >= 99.5 % of the pixels (measured 0.9994 after one
-sample, profiles/parity_report.json; the others took a different, equally valid path after a one-ulp
-transcendental difference); the 4K frame, which the
+film bit-identical to the oracle's after two samples; the 4K frame, which the
 oracle cannot render in test time, is checked through properties: bitwise repeatability, exact
 per-bounce ray counts from call to call, one path per pixel, no dropped stack pushes, no NaNs."""
 import numpy as np
@@ -93,8 +91,7 @@ def test_one_sample_film_matches_oracle(pt, ora, gpu_ctx, party):
         ref, _ = ora.render(desc, w, h, it, ref, nthreads=8)
     film = gpu_ctx.film_download(w, h)
     assert np.isfinite(film).all() and ref.mean() > 1e-3
-    close = (np.abs(film - ref) <= 1e-4 + 1e-3 * np.abs(ref)).all(axis=2)
-    assert close.mean() >= 0.995, f"only {close.mean():.4f} of the pixels agree"
+    assert np.array_equal(film.view(np.uint32), ref.view(np.uint32))
     st = gpu_ctx.stats()
     assert st.nan_pixels == 0 and st.stack_drops == 0
 

@@ -8,8 +8,8 @@ barycentrics are in fact bit-equal, which the tests also require).  Any-hit flag
 box like the reference, flags equal except <= 1e-5 of the rays; mode 3 also skips boxes that start
 beyond t_max * (1 + 2^-12), which could only turn "occluded" into "free" (an occluder within rounding of
 t_max, see pt_set_trace_mode): the same bar, <= 1e-5 of the rays.  Rendered film of one
-sample within |d| <= 1e-4 + 1e-3 |ref| of the oracle's film on >= 99.8 % of the pixels in both modes
-(measured: the same shares as mode 0, 0.9994 .. 1.0); profiles/parity_report.json."""
+sample: bit-identical to the oracle's except on pixels whose path met such a tie, at most 1e-3 of them
+(measured: 0 to 3 of 129 600 pixels after four samples, tools/film_exactness.py)."""
 import numpy as np
 import pytest
 
@@ -134,8 +134,8 @@ def test_wide_one_sample_film_matches_oracle(pt, ora, gpu_ctx, scene_factory, ti
         gpu_ctx.set_trace_mode(0)
     ref, _ = ora.render(desc, w, h, 0, nthreads=8)
     assert np.isfinite(film).all() and ref.mean() > 1e-3
-    close = (np.abs(film - ref) <= 1e-4 + 1e-3 * np.abs(ref)).all(axis=2)
-    assert close.mean() >= 0.998, f"{name} mode {mode}: only {close.mean():.4f} of the pixels agree"
+    differ = (film.view(np.uint32) != ref.view(np.uint32)).any(axis=2)
+    assert differ.mean() <= 1e-3, f"{name} mode {mode}: {int(differ.sum())} of {w * h} pixels differ from the oracle's film"
     assert st.paths == w * h and st.nan_pixels == 0 and st.stack_drops == 0
 
 
