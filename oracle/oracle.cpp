@@ -1740,6 +1740,11 @@ int ora_trace_closest(const pt_scene_desc *desc, const pt_ray *rays, size_t n, p
     }
     return 0;
 }
+// The constants this file uses in place of src/math/constants.h, in that header's order (those it has a use for; 0 otherwise).
+void ora_constants(float out[9]) {
+    const float v[9] = {SMALL_EPSILON, EPSILON, 0.0f, PI, 0.0f, 0.0f, INV_PI, 0.0f, INV_SQRT3};
+    for (int i = 0; i < 9; ++i) out[i] = v[i];
+}
 void ora_sincos_azimuth(const float *phi, size_t n, float *sin_phi, float *cos_phi) {
     for (size_t i = 0; i < n; ++i) SinCosAzimuth(phi[i], sin_phi[i], cos_phi[i]);
 }

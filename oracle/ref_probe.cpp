@@ -11,6 +11,7 @@
 //   ref_probe obj <file.obj>           tinyobj::ObjReader on the file: attrib arrays and per-corner indices
 //   ref_probe image <file> <out.raw>   stbi_load(file, 3 channels): "w h channels_in_file", pixels to out.raw
 //   ref_probe png <w> <h> <out.png>    stbi_write_png of a fixed test pattern (RGB)
+//   ref_probe constants                bit patterns of the fp32 constants of src/math/constants.h
 #include <cstdint>
 #include <cstddef>
 #include <cstdio>
@@ -21,6 +22,7 @@
 
 #include "utils/cl_happy.h"
 #include "math/hash.h"
+#include "math/constants.h"
 #include "utils/stack.h"
 #include "tiny_obj_loader.h"
 #include "stb_image.h"
@@ -29,6 +31,16 @@
 int main(int argc, char **argv) {
     if (argc < 2) return 2;
     const std::string cmd = argv[1];
+    if (cmd == "constants") {
+        const float v[] = {Math::SMALL_EPSILON, Math::EPSILON, Math::ONE_MINUS_EPSILON, Math::PI, Math::HALF_PI, Math::TWO_PI, Math::INV_PI,
+                           Math::SQRT3, Math::INV_SQRT3};
+        for (float f : v) {
+            uint32_t bits;
+            memcpy(&bits, &f, 4);
+            printf("%u\n", bits);
+        }
+        return 0;
+    }
     if (cmd == "hash") {
         const int n = atoi(argv[2]);
         uint32_t x = 0x12345u;

@@ -36,6 +36,9 @@ def main():
     pairs = np.array([[int(x) for x in ln.split()] for ln in run("hash", 4096).splitlines()], np.uint64)
     out["hash_in"], out["hash_out"] = pairs[:, 0].astype(np.uint32), pairs[:, 1].astype(np.uint32)
 
+    # SMALL_EPSILON, EPSILON, ONE_MINUS_EPSILON, PI, HALF_PI, TWO_PI, INV_PI, SQRT3, INV_SQRT3 (src/math/constants.h)
+    out["constants_bits"] = np.array([int(x) for x in run("constants").split()], np.uint32)
+
     script = list(range(1, 71)) + [0] * 66 + [7, 8, 0, 9, 0, 0, 0]  # 70 pushes into 64 slots, 66 pops, then a few more
     lines = run("stack", *script).splitlines()
     out["stack_script"] = np.array(script, np.uint32)

@@ -112,3 +112,18 @@ def test_png_writer_stores_the_same_pixels_as_stb_image_write(pt, pins, tmp_path
     pt.save_png(str(out), rgba)
     ours = np.asarray(Image.open(out).convert("RGB"))
     assert np.array_equal(ours, px)
+
+
+def test_constants_match_reference_header(ora, pins):
+    """src/math/constants.h compiled as it stands: the bit patterns of the constants the oracle restates
+    (SMALL_EPSILON, EPSILON, PI, INV_PI, INV_SQRT3 - the last one a double literal narrowed to float)."""
+    import ctypes as C
+    out = (C.c_float * 9)()
+    fn = ora.lib().ora_constants
+    fn.restype = None
+    fn(out)
+    mine = np.array(list(out), np.float32).view(np.uint32)
+    ref = pins["constants_bits"]
+    for k in (0, 1, 3, 6, 8):
+        assert mine[k] == ref[k], k
+    assert ref.view(np.float32)[1] == np.float32(1e-5) and ref.view(np.float32)[3] == np.float32(np.pi)
