@@ -67,13 +67,21 @@ public:
 private:
     const std::string &s;
     size_t p = 0;
+    int depth = 0;  // nesting of the value being parsed: bounded, so that a hostile file cannot exhaust the stack
     [[noreturn]] void Error(const char *what) const { throw Exception("JSON: " + std::string(what) + " at byte " + std::to_string(p)); }
     void Skip() {
         while (p < s.size() && (s[p] == ' ' || s[p] == '\t' || s[p] == '\n' || s[p] == '\r')) ++p;
     }
+    struct Nest {
+        int &d;
+        explicit Nest(int &depth) : d(depth) { ++d; }
+        ~Nest() { --d; }
+    };
     Json Value() {
         Skip();
         if (p >= s.size()) Error("unexpected end");
+        const Nest nest(depth);
+        if (depth > 200) Error("nesting deeper than 200 levels");
         const char c = s[p];
         Json v;
         if (c == '{') {
@@ -183,14 +191,16 @@ std::string Lower(std::string s) {
 }
 
 std::string Base64Decode(const std::string &in, size_t from) {
-    static int table[256];
-    static bool ready = false;
-    if (!ready) {
-        for (int &t : table) t = -1;
-        const char *abc = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
-        for (int i = 0; i < 64; ++i) table[(unsigned char)abc[i]] = i;
-        ready = true;
-    }
+    struct Table {
+        int v[256];
+        Table() {
+            for (int &t : v) t = -1;
+            const char *abc = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+            for (int i = 0; i < 64; ++i) v[(unsigned char)abc[i]] = i;
+        }
+    };
+    static const Table t;  // initialised once, thread-safe
+    const int *table = t.v;
     std::string out;
     out.reserve((in.size() - from) * 3 / 4);
     unsigned acc = 0;
@@ -383,6 +393,8 @@ public:
         Camera &c = S.GetCamera();  // ParseCamera, scene.cpp:175-233
         c.GetFilm().width = width > 0 ? width : file_w;
         c.GetFilm().height = height > 0 ? height : file_h;
+        if (c.GetFilm().width < 1 || c.GetFilm().height < 1 || c.GetFilm().width > 65536 || c.GetFilm().height > 65536)
+            throw Exception("scene '" + path + "': film size must lie in 1..65536 each way");
         c.SetDefaults(Vec3From(*cam, "EYE", {0, 0, 0}), Vec3From(*cam, "LOOKAT", {0, 0, -1}), Vec3From(*cam, "UP", {0, 1, 0}), float(NumberOr(*cam, "FOVY", 45.0)));
         c.ResetDefaults();
 
@@ -637,6 +649,12 @@ private:
         std::string dir;
         std::vector<std::string> buffers;
     };
+    // a member that must be there (and be of the right kind): malformed files end in an Exception, never in a null dereference
+    static const Json &Need(const Json &o, const char *key, Json::Type type) {
+        const Json *v = o.find(key);
+        if (!v || v->type != type) throw Exception(std::string("glTF: missing or malformed \"") + key + "\"");
+        return *v;
+    }
     static size_t ComponentSize(int type) {
         switch (type) {
             case 5120: case 5121: return 1;
@@ -655,8 +673,12 @@ private:
     }
     // element-wise read of an accessor, honouring byteStride (IterateAccessor, mesh/gltf_model.h:189-261); values are converted, not normalised
     static void ReadAccessor(const Gltf &g, int index, std::vector<double> &out, int &ncomp, size_t &count) {
-        const Json &acc = g.j.find("accessors")->arr.at(size_t(index));
-        const Json &view = g.j.find("bufferViews")->arr.at(size_t(NumberOr(acc, "bufferView", 0)));
+        const std::vector<Json> &accessors = Need(g.j, "accessors", Json::Array).arr, &views = Need(g.j, "bufferViews", Json::Array).arr;
+        if (index < 0 || size_t(index) >= accessors.size()) throw Exception("glTF: accessor index out of range");
+        const Json &acc = accessors[size_t(index)];
+        const size_t view_index = size_t(NumberOr(acc, "bufferView", 0));
+        if (view_index >= views.size()) throw Exception("glTF: bufferView index out of range");
+        const Json &view = views[view_index];
         const int ctype = int(NumberOr(acc, "componentType", 5126));
         const size_t size = ComponentSize(ctype);
         ncomp = ComponentCount(StringOr(acc, "type", "SCALAR"));
@@ -664,7 +686,10 @@ private:
         size_t stride = size_t(NumberOr(view, "byteStride", 0));
         if (stride == 0) stride = size * size_t(ncomp);
         const size_t start = size_t(NumberOr(view, "byteOffset", 0)) + size_t(NumberOr(acc, "byteOffset", 0));
-        const std::string &buf = g.buffers.at(size_t(NumberOr(view, "buffer", 0)));
+        const size_t buffer_index = size_t(NumberOr(view, "buffer", 0));
+        if (buffer_index >= g.buffers.size()) throw Exception("glTF: buffer index out of range");
+        const std::string &buf = g.buffers[buffer_index];
+        if (count > buf.size()) throw Exception("glTF: accessor count exceeds its buffer");  // every element takes at least a byte
         out.resize(count * size_t(ncomp));
         for (size_t e = 0; e < count; ++e)
             for (int c = 0; c < ncomp; ++c) {
@@ -684,14 +709,21 @@ private:
             }
     }
     std::string ImageBytes(const Gltf &g, int index) const {
-        const Json &im = g.j.find("images")->arr.at(size_t(index));
-        if (const Json *uri = im.find("uri")) {
+        const std::vector<Json> &images = Need(g.j, "images", Json::Array).arr;
+        if (index < 0 || size_t(index) >= images.size()) throw Exception("glTF: image index out of range");
+        const Json &im = images[size_t(index)];
+        if (const Json *uri = im.find("uri"); uri && uri->is_string()) {
             if (uri->str.compare(0, 5, "data:") == 0) return Base64Decode(uri->str, uri->str.find(',') + 1);
             return ReadFile(Join(g.dir, uri->str));
         }
-        const Json &view = g.j.find("bufferViews")->arr.at(size_t(NumberOr(im, "bufferView", 0)));
+        const std::vector<Json> &views = Need(g.j, "bufferViews", Json::Array).arr;
+        const size_t view_index = size_t(NumberOr(im, "bufferView", 0));
+        if (view_index >= views.size()) throw Exception("glTF: bufferView index out of range");
+        const Json &view = views[view_index];
         const size_t off = size_t(NumberOr(view, "byteOffset", 0)), len = size_t(NumberOr(view, "byteLength", 0));
-        return g.buffers.at(size_t(NumberOr(view, "buffer", 0))).substr(off, len);
+        const size_t buffer_index = size_t(NumberOr(view, "buffer", 0));
+        if (buffer_index >= g.buffers.size() || off > g.buffers[buffer_index].size()) throw Exception("glTF: image bufferView out of range");
+        return g.buffers[buffer_index].substr(off, len);
     }
 
     void LoadGltf(const std::string &path, bool face_normals, bool invert_normals, const Mat4 &instance_transform, int override_material,
@@ -711,22 +743,32 @@ private:
         if (const Json *meshes = g.j.find("meshes"))
             for (const Json &mesh : meshes->arr) {
                 std::vector<Prim> prims;
-                for (const Json &prim : mesh.find("primitives")->arr) {
+                for (const Json &prim : Need(mesh, "primitives", Json::Array).arr) {
                     if (int(NumberOr(prim, "mode", 4)) != 4) continue;
-                    const Json &attrs = *prim.find("attributes");
+                    const Json &attrs = Need(prim, "attributes", Json::Object);
                     std::vector<double> pos, nrm, uv, idx;
                     int nc;
                     size_t vc, cnt;
-                    ReadAccessor(g, int(attrs.find("POSITION")->num), pos, nc, vc);
+                    ReadAccessor(g, int(Need(attrs, "POSITION", Json::Number).num), pos, nc, vc);
+                    if (nc != 3) throw Exception("glTF: POSITION must be VEC3");
                     const bool use_face = face_normals || !attrs.has("NORMAL");
-                    if (!use_face) ReadAccessor(g, int(attrs.find("NORMAL")->num), nrm, nc, cnt);
+                    if (!use_face) {
+                        ReadAccessor(g, int(Need(attrs, "NORMAL", Json::Number).num), nrm, nc, cnt);
+                        if (nc != 3 || cnt != vc) throw Exception("glTF: NORMAL must be VEC3 with one entry per vertex");
+                    }
                     const bool has_uv = attrs.has("TEXCOORD_0");
-                    if (has_uv) ReadAccessor(g, int(attrs.find("TEXCOORD_0")->num), uv, nc, cnt);
+                    if (has_uv) {
+                        ReadAccessor(g, int(Need(attrs, "TEXCOORD_0", Json::Number).num), uv, nc, cnt);
+                        if (nc != 2 || cnt != vc) throw Exception("glTF: TEXCOORD_0 must be VEC2 with one entry per vertex");
+                    }
                     std::vector<uint32_t> indices;
                     if (prim.has("indices")) {
-                        ReadAccessor(g, int(prim.find("indices")->num), idx, nc, cnt);
+                        ReadAccessor(g, int(Need(prim, "indices", Json::Number).num), idx, nc, cnt);
                         indices.resize(idx.size());
-                        for (size_t k = 0; k < idx.size(); ++k) indices[k] = uint32_t(idx[k]);
+                        for (size_t k = 0; k < idx.size(); ++k) {
+                            if (!(idx[k] >= 0.0 && idx[k] < double(vc))) throw Exception("glTF: vertex index out of range");
+                            indices[k] = uint32_t(idx[k]);
+                        }
                     } else {
                         indices.resize(vc);
                         for (size_t k = 0; k < vc; ++k) indices[k] = uint32_t(k);
@@ -779,8 +821,10 @@ private:
                 pm.type = PT_MAT_METALLIC_ROUGHNESS;  // absent textures fall back to texture 0
                 const Json *pbr = mat.find("pbrMetallicRoughness");
                 auto source_of = [&](const Json &ref) {
-                    const Json &tex = g.j.find("textures")->arr.at(size_t(NumberOr(ref, "index", 0)));
-                    return int(NumberOr(tex, "source", 0));
+                    const std::vector<Json> &textures = Need(g.j, "textures", Json::Array).arr;
+                    const size_t index = size_t(NumberOr(ref, "index", 0));
+                    if (index >= textures.size()) throw Exception("glTF: texture index out of range");
+                    return int(NumberOr(textures[index], "source", 0));
                 };
                 if (pbr && pbr->has("baseColorTexture")) {
                     const int src = source_of(*pbr->find("baseColorTexture"));
@@ -811,17 +855,24 @@ private:
         // ---- node hierarchy: world = parent * (T * R * S * matrix), visited like ForEachNode (roots pushed in order, popped from the back)
         struct Node { Mat4 world; int mesh; std::vector<int> children; };
         std::vector<Node> nodes;
-        const Json *jnodes = g.j.find("nodes");
+        const std::vector<Json> &jnodes = Need(g.j, "nodes", Json::Array).arr;
+        auto numbers = [](const Json &v, size_t count, float *out) {
+            if (v.type != Json::Array || v.arr.size() < count) throw Exception("glTF: node transform with too few numbers");
+            for (size_t k = 0; k < count; ++k) out[k] = float(v.arr[k].num);
+        };
         std::function<int(int, const Mat4 &)> load_node = [&](int ni, const Mat4 &parent) {
-            const Json &n = jnodes->arr.at(size_t(ni));
+            if (ni < 0 || size_t(ni) >= jnodes.size()) throw Exception("glTF: node index out of range");
+            if (nodes.size() > jnodes.size() * 64 + 4096) throw Exception("glTF: node hierarchy is not a tree");  // a cycle would recurse for ever
+            const Json &n = jnodes[size_t(ni)];
             const Mat4 I = Mat4::Identity();
             Vec3 t{0, 0, 0}, s{1, 1, 1};
             float q[4] = {0, 0, 0, 1};
             Mat4 matrix = I;
-            if (const Json *v = n.find("translation")) t = {float(v->arr[0].num), float(v->arr[1].num), float(v->arr[2].num)};
-            if (const Json *v = n.find("scale")) s = {float(v->arr[0].num), float(v->arr[1].num), float(v->arr[2].num)};
-            if (const Json *v = n.find("rotation")) for (int k = 0; k < 4; ++k) q[k] = float(v->arr[size_t(k)].num);
-            if (const Json *v = n.find("matrix")) for (int k = 0; k < 16; ++k) matrix.m[k] = float(v->arr[size_t(k)].num);
+            float f3[3];
+            if (const Json *v = n.find("translation")) { numbers(*v, 3, f3); t = {f3[0], f3[1], f3[2]}; }
+            if (const Json *v = n.find("scale")) { numbers(*v, 3, f3); s = {f3[0], f3[1], f3[2]}; }
+            if (const Json *v = n.find("rotation")) numbers(*v, 4, q);
+            if (const Json *v = n.find("matrix")) numbers(*v, 16, matrix.m);
             const Mat4 local = Mul(Mul(Mul(Translate(I, t), FromQuat(q[0], q[1], q[2], q[3])), Scale(I, s)), matrix);
             Node node;
             node.world = Mul(parent, local);
@@ -837,7 +888,9 @@ private:
         };
         std::vector<int> stack;
         const int scene_index = int(NumberOr(g.j, "scene", 0));
-        for (const Json &r : g.j.find("scenes")->arr.at(size_t(scene_index)).find("nodes")->arr) stack.push_back(load_node(int(r.num), Mat4::Identity()));
+        const std::vector<Json> &scenes = Need(g.j, "scenes", Json::Array).arr;
+        if (scene_index < 0 || size_t(scene_index) >= scenes.size()) throw Exception("glTF: scene index out of range");
+        for (const Json &r : Need(scenes[size_t(scene_index)], "nodes", Json::Array).arr) stack.push_back(load_node(int(r.num), Mat4::Identity()));
         std::vector<int> order;
         while (!stack.empty()) {
             const int cur = stack.back();

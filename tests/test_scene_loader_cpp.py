@@ -168,8 +168,52 @@ def test_loader_errors_are_reported(pt, tmp_path):
     nocam.write_text('{"materials": {}, "objects": []}')
     with pytest.raises(pt.PtError, match="camera"):
         pt.HostScene.load(str(nocam))
+    zero = tmp_path / "zero.json"
+    zero.write_text('{"camera": {"film": {"WIDTH": 0, "HEIGHT": 4}}, "objects": []}')
+    with pytest.raises(pt.PtError, match="film size"):
+        pt.HostScene.load(str(zero))
     with pytest.raises(pt.PtError, match="no image decoder"):
         pt.HostScene.load(_textured_scene(tmp_path), decode_images=False)
+
+
+def test_malformed_files_end_in_an_error_not_a_crash(pt, tmp_path):
+    """Damaged input reaches the caller as PtError: unbounded nesting, glTF members that are missing, indices
+    that point outside their arrays, vertex indices beyond the vertex count, node cycles."""
+    deep = tmp_path / "deep.json"
+    deep.write_text("[" * 100000)
+    with pytest.raises(pt.PtError, match="nesting"):
+        pt.HostScene.load(str(deep))
+    scene_path = _textured_scene(tmp_path)
+    good = json.loads((tmp_path / "t.gltf").read_text())
+    pt.HostScene.load(scene_path)
+
+    def damaged(edit, match):
+        g = json.loads(json.dumps(good))
+        edit(g)
+        (tmp_path / "t.gltf").write_text(json.dumps(g))
+        with pytest.raises(pt.PtError, match=match):
+            pt.HostScene.load(scene_path)
+
+    damaged(lambda g: g.pop("accessors"), "accessors")
+    damaged(lambda g: g.pop("bufferViews"), "bufferViews")
+    damaged(lambda g: g["meshes"][0].pop("primitives"), "primitives")
+    damaged(lambda g: g["meshes"][0]["primitives"][0].pop("attributes"), "attributes")
+    damaged(lambda g: g["meshes"][0]["primitives"][0]["attributes"].pop("POSITION"), "POSITION")
+    damaged(lambda g: g["meshes"][0]["primitives"][0].update(indices=9), "accessor index")
+    damaged(lambda g: g["accessors"][0].update(bufferView=7), "bufferView index")
+    damaged(lambda g: g["bufferViews"][1].update(buffer=3), "buffer index")
+    damaged(lambda g: g["accessors"][2].update(count=1 << 40), "exceeds")
+    damaged(lambda g: g["accessors"][0].update(count=3), "one entry per vertex|out of range")  # indices then name vertex 3 of 3
+    damaged(lambda g: g["accessors"][1].update(type="VEC3"), "TEXCOORD_0")
+    damaged(lambda g: g["textures"].pop(), "texture index")
+    damaged(lambda g: g["images"].pop(), "image index")
+    damaged(lambda g: g.pop("scenes"), "scenes")
+    damaged(lambda g: g.update(scene=2), "scene index")
+    damaged(lambda g: g["scenes"][0].update(nodes=[5]), "node index")
+    damaged(lambda g: g["nodes"][0].update(children=[0]), "not a tree")
+    damaged(lambda g: g["nodes"][0].update(matrix=[1, 0, 0]), "too few numbers")
+    (tmp_path / "t.gltf").write_text(json.dumps(good))
+    pt.HostScene.load(scene_path)
 
 
 @pytest.mark.parametrize("name,rel", [("teapot", "teapot/teapot.json"), ("cornell", "cornell.json"), ("pbr_metallic", "pbr_metallic.json"),
