@@ -35,6 +35,14 @@
 #ifndef PT_STRAIGHT_PUSH
 #define PT_STRAIGHT_PUSH 1
 #endif
+#ifndef PT_POP_FIRST
+// 1: a lane without a node pops before the wave votes on the next box round and takes part in that round.
+// 0: the pop runs between the issue of the node loads and their use, where its LDS round trip is hidden, and
+// the lane joins one round later.  Measured on the bench's ray batch: 1 is 5-6 % faster in both layouts (a
+// ray spends 6 of its 34 steps popping); popping inside the box test itself, for lanes whose test hit no
+// child, costs the 4-wide kernel 16 more spilled registers and 12 %.
+#define PT_POP_FIRST 1
+#endif
 #ifndef PT_POSTPONE_LEAVES
 #define PT_POSTPONE_LEAVES 0  // 1: lanes set leaves aside and keep testing boxes (see Traversal::kPostpone)
 #endif
@@ -614,14 +622,13 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
         PT_PHASE(ev, 7);
         PT_TSTAMP(5);
 
-        // ---- box-test rounds, while enough lanes take part.  The node loads are issued before
-        // the pops so that the LDS round trip hides behind them.
+        // ---- box-test rounds, while enough lanes take part (PT_POP_FIRST says where the pops go)
         const unsigned long long active_mask = __builtin_amdgcn_ballot_w64(active);
         // a wave that can no longer refill keeps the loop going for half of the lanes it has left
         const int vote_int = (PT_DRAIN_ALL_OPS && !can_refill) ? max(1, (__builtin_popcountll(active_mask) + 1) >> 1) : PT_VOTE_INT;
         for (;;) {
             if (active) tr.set_leaf_aside();
-#ifdef PT_POP_FIRST
+#if PT_POP_FIRST
             if (active && tr.wants_pop()) {
                 PT_PHASE(ev, 3);
                 tr.pop(stk);
@@ -636,7 +643,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
 #pragma unroll
                 for (int r = 0; r < kNodeRegs; ++r) nq[r] = np[r];
             }
-#ifndef PT_POP_FIRST
+#if !PT_POP_FIRST
             if (active && tr.wants_pop()) {
                 PT_PHASE(ev, 3);
                 tr.pop(stk);

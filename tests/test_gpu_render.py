@@ -18,6 +18,7 @@ def _films(pt, ora, gpu_ctx, hs, w, h, iterations):
     desc = hs.desc()
     gpu_ctx.upload(desc)
     gpu_ctx.integrator_init(w, h)
+    gpu_ctx.reset_stats()  # the context is shared with tests that overflow the stack on purpose
     ref = None
     for it in range(iterations):
         gpu_ctx.render(w, h, it)
