@@ -60,6 +60,7 @@ PTD V3 heat_map_color(int depth, int max_depth) {  // debug.cu:42-49
 
 // Stream i = path-slot order (8x8 pixel tiles, one per wave), so a wave's rays form a bundle.
 struct DebugIO {
+    static constexpr bool kExactDistance = true;
     const DScene &S;
     DebugParams p;
     float *image;    // W*H*3, may be null

@@ -101,6 +101,7 @@ PTD void flush_events(DevStats *stats, const LaneEvents &ev) {
 // ------------------------------------------------------------- batch queries
 template <bool COUNT>
 struct ClosestIO {
+    static constexpr bool kExactDistance = true;
     const DScene &S;
     const pt_ray *rays;
     pt_hit *hits;
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(64, PT_QUERY_WAVES_PER_SIMD) void k_trace_closest(D
 
 template <bool COUNT>
 struct AnyIO {
+    static constexpr bool kExactDistance = true;
     const pt_ray *rays;
     uint8_t *occluded;
     TraceCounters *counters;
@@ -296,6 +298,7 @@ __global__ __launch_bounds__(64) void k_generate(DScene S, PathState P, BounceCo
 // A miss ends the path on the spot (the reference routes it through EmissiveHitKernel, which adds
 // throughput * 0, path_trace.cu:351-356: a no-op unless the throughput is not finite).
 struct ExtendIO {
+    static constexpr bool kExactDistance = false;  // a path keeps (instance, u, v, record) of its hit, not the distance
     const DScene &S;
     const PathState &P;
     BounceCounters *bc;
@@ -752,6 +755,7 @@ __global__ __launch_bounds__(64) void k_shade(DScene S, PathState P, BounceCount
 // The visibility half of next-event estimation (path_trace.cu:221-243): IntersectScene<ANY> with
 // t_max = dist - 1e-4; an unoccluded sample adds its contribution to the path's radiance.
 struct ShadowIO {
+    static constexpr bool kExactDistance = true;
     const PathState &P;
     PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax, uint32_t &tag) {
         const uint32_t slot = P.sh_q[i];

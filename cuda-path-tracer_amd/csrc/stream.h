@@ -86,7 +86,8 @@ __device__ unsigned long long g_trace_stamps[8];
 // triangle, and the winner's distance and barycentrics come from the same triangle test on the same
 // record.  The wide layout also spends what the reference leaves on the table: inside an instance
 // the search is bounded by the best hit of the instances before it (object-space and world-space
-// distances are the same quantity, math/ray.h:19-21).
+// distances are the same quantity, math/ray.h:19-21; the bound carries a margin for their different
+// rounding, see op_level).
 template <int MODE, bool COUNT, int DEPTH = kLdsDepth, bool WIDE = false>
 struct Traversal {
     V3 o, d, iw;     // world-space ray and reciprocal direction
@@ -99,6 +100,7 @@ struct Traversal {
     float lu, lv;
     uint32_t cur_mat, cur_type;  // of the instance being searched
     bool lfound;     // WIDE: the current instance has produced a candidate
+    bool prov;       // WIDE, closest hit: `best` is still the winner's object-space distance (op_level)
     int cur_inst;
     int sp, base;
     bool in_blas;
@@ -138,6 +140,7 @@ struct Traversal {
         lrec = 0;
         lu = lv = 0.0f;
         lfound = false;
+        prov = false;
         cur_inst = -1;
         sp = 0;
         base = 0;
@@ -332,7 +335,7 @@ struct Traversal {
         co = xform(inv, o, 1.0f);
         cd = xform(inv, d, 0.0f);
         ci = mk3(1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z);
-        if (MODE == MODE_CLOSEST) cbest = WIDE ? best : FLT_MAX;
+        if (MODE == MODE_CLOSEST) cbest = WIDE ? wide_bound() : FLT_MAX;
         lfound = false;
         base = sp;
         in_blas = true;
@@ -410,36 +413,68 @@ struct Traversal {
     // world-space distance with the best of the other instances, and the ray returns to the
     // TLAS (kernel/intersection.h:139-149, :190-194).  In the TLAS: the ray is finished.
     // Returns true when finished.
+    //
+    // The 4-wide layout bounds the search inside an instance, and the pops of the top level, by the best
+    // distance so far, which the reference does not (it starts every instance from "no hit" and compares
+    // the candidates by the distance it recomputes in world space from each).  The two distances are the
+    // same quantity but not the same bits (2e-5 apart for a strongly scaled instance), so the bound
+    // carries a margin, and a candidate that survives it still competes by the recomputed distance, as
+    // in the reference.  What the layout saves: the first candidate of a ray has nothing to compete with,
+    // so its instance is left without touching memory and its recomputed distance (two dependent
+    // gathers) is taken only when a second candidate turns up or when the ray finishes - there always
+    // with EXACT_T, otherwise only for a hit so close to the origin that the recomputed distance could
+    // come out negative, which the reference reports as a miss.
+    static constexpr float kWideBoundMargin = 2.44140625e-4f;  // 2^-12
+    PTD float wide_bound() const { return best + fabsf(best) * kWideBoundMargin; }  // FLT_MAX stays "no bound" (+inf)
+    PTD float world_distance(const DScene &S, uint32_t rec, float u, float v, int inst) const {
+        const V3 lp = tri_point(S.tris, rec, u, v);
+        const float4 *fp = reinterpret_cast<const float4 *>(S.fwd + inst);
+        const M34 T = load_m34(fp[0], fp[1], fp[2]);
+        return dot(xform(T, lp, 1.0f) - o, d);
+    }
+    PTD void take_candidate(float t) {
+        best = t;
+        hit.t = t;
+        hit.u = lu;
+        hit.v = lv;
+        hit.rec = lrec;
+        hit.inst = cur_inst;
+        hit.prim = lprim;
+        hit.mat = cur_mat;
+        hit.type = cur_type;
+    }
+    template <bool EXACT_T = true>
     PTD bool op_level(const DScene &S) {
         if (in_blas) {
             if (MODE == MODE_ANY && lfound) {  // the first instance that reports a hit ends the search (kernel/intersection.h:196-200, :229-232)
-                const V3 lp = tri_point(S.tris, lrec, lu, lv);
-                const float4 *fp = reinterpret_cast<const float4 *>(S.fwd + cur_inst);
-                const M34 T = load_m34(fp[0], fp[1], fp[2]);
-                const float wt = dot(xform(T, lp, 1.0f) - o, d);
+                const float wt = world_distance(S, lrec, lu, lv, cur_inst);
                 found = !(wt < 0.0f || wt == FLT_MAX);
                 return true;
             }
             if (MODE == MODE_CLOSEST) {
-                if (WIDE ? lfound : cbest < FLT_MAX) {
-                    const V3 lp = tri_point(S.tris, lrec, lu, lv);
-                    const float4 *fp = reinterpret_cast<const float4 *>(S.fwd + cur_inst);
-                    const M34 T = load_m34(fp[0], fp[1], fp[2]);
-                    const V3 wp = xform(T, lp, 1.0f);
-                    const float wt = dot(wp - o, d);
-                    if (wt < best) {
-                        best = wt;
-                        hit.t = wt;
-                        hit.u = lu;
-                        hit.v = lv;
-                        hit.rec = lrec;
-                        hit.inst = cur_inst;
-                        hit.prim = lprim;
-                        hit.mat = cur_mat;
-                        hit.type = cur_type;
+                if constexpr (WIDE) {
+                    if (lfound) {
+                        if (hit.inst < 0) {
+                            take_candidate(cbest);
+                            prov = true;
+                        } else {
+                            const float wt = world_distance(S, lrec, lu, lv, cur_inst);
+                            if (prov) {
+                                best = world_distance(S, hit.rec, hit.u, hit.v, hit.inst);
+                                hit.t = best;
+                                prov = false;
+                            }
+                            if (wt < best) take_candidate(wt);
+                        }
                     }
+                    cbest = wide_bound();
+                } else {
+                    if (cbest < FLT_MAX) {
+                        const float wt = world_distance(S, lrec, lu, lv, cur_inst);
+                        if (wt < best) take_candidate(wt);
+                    }
+                    cbest = best;
                 }
-                cbest = best;
             }
             in_blas = false;
             co = o;
@@ -447,7 +482,14 @@ struct Traversal {
             ci = iw;
             base = 0;
         }
-        return sp == 0;
+        if (sp != 0) return false;
+        if constexpr (MODE == MODE_CLOSEST && WIDE) {
+            if (prov && (EXACT_T || best <= kAnyHitSettles)) {
+                best = world_distance(S, hit.rec, hit.u, hit.v, hit.inst);
+                hit.t = best;
+            }
+        }
+        return true;
     }
 };
 
@@ -455,6 +497,7 @@ struct Traversal {
 // from a global cursor, and every lane that finishes its ray takes the next index of the
 // chunk while its neighbours keep traversing (refill happens once at least kRefillMin lanes
 // are idle, so the reload code runs for a meaningful share of the wave).
+//   IO::kExactDistance                  done() reads the hit's distance (Traversal::op_level)
 //   io.load(i, o, d, tmax, tag)         ray i of the stream; tag travels with the ray to done()
 //   io.done(i, tag, trav, valid)        called once per ray by the lane that traced it
 //   io.flush()                          called by all 64 lanes at every refill point
@@ -475,6 +518,9 @@ constexpr uint32_t kNoRayBits = 0x7FC0DEADu;  // t_max bit pattern (a NaN no com
 #endif
 #ifndef PT_VOTE_RARE
 #define PT_VOTE_RARE 8   // lanes that make an instance enter / level change round worth running
+#endif
+#ifndef PT_VOTE_LEVEL
+#define PT_VOTE_LEVEL PT_VOTE_RARE
 #endif
 constexpr int kRefillMin = PT_REFILL_MIN;
 
@@ -713,11 +759,11 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
                 tr.op_enter(S);
             }
         }
-        if (n_lvl > 0 && (n_lvl >= PT_VOTE_RARE || n_lvl == n_max || drain || (can_refill && n_lvl + idle >= kRefillMin))) {
+        if (n_lvl > 0 && (n_lvl >= PT_VOTE_LEVEL || n_lvl == n_max || drain || (can_refill && n_lvl + idle >= kRefillMin))) {
             if (w_deep) tr.deep_pop(stk);
             if (w_lvl) {
                 PT_PHASE(ev, 4);
-                if (tr.op_level(S)) {
+                if (tr.template op_level<IO::kExactDistance>(S)) {
                     active = false;
                     io.done(ray_index, ray_tag, tr, MODE == MODE_ANY ? tr.found : tr.closest_valid());
                 }

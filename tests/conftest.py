@@ -97,7 +97,7 @@ def rays_from_arrays(pt, origins, directions, tmax=None):
 
 
 @pytest.fixture(scope="session")
-def gpu_ctx(pt):
+def _session_gpu_ctx(pt):
     import torch
 
     if not torch.cuda.is_available():
@@ -105,6 +105,14 @@ def gpu_ctx(pt):
     ctx = pt.Context(0)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture()
+def gpu_ctx(_session_gpu_ctx):
+    """One context for the whole session; every test starts with its counters at zero (some tests overflow the
+    traversal stack on purpose, and the drop counter would otherwise leak into whichever test runs next)."""
+    _session_gpu_ctx.reset_stats()
+    return _session_gpu_ctx
 
 
 class DeviceBuf:
