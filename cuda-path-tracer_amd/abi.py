@@ -149,7 +149,7 @@ PT_SYMBOLS = [
     "pt_render_async", "pt_render_batch", "pt_set_render_window", "pt_film_download", "pt_film_copy_to_device", "pt_film_copy_from_device", "pt_film_upload", "pt_display_download", "pt_tonemap",
     "pt_trace_closest", "pt_trace_any", "pt_resolve_hits", "pt_trace_closest_counted", "pt_trace_any_counted", "pt_trace_closest_static", "pt_trace_closest_host",
     "pt_trace_any_host", "pt_resolve_hits_host", "pt_generate_incoherent_rays", "pt_capture_bounce_rays", "pt_capture_shadow_rays",
-    "pt_set_trace_mode", "pt_get_trace_layout", "pt_set_texture_filter", "pt_film_reduce", "pt_rccl_unique_id", "pt_rccl_comm_create", "pt_rccl_comm_destroy", "pt_debug_render", "pt_bvh_build", "pt_bvh_sizes", "pt_bvh_get", "pt_bvh_timing", "pt_bvh_free"]
+    "pt_set_trace_mode", "pt_set_texture_filter", "pt_film_reduce", "pt_rccl_unique_id", "pt_rccl_comm_create", "pt_rccl_comm_destroy", "pt_debug_render", "pt_bvh_build", "pt_bvh_sizes", "pt_bvh_get", "pt_bvh_timing", "pt_bvh_free"]
 PTH_SYMBOLS = [
     "pth_last_error", "pth_transform_matrix", "pth_matrix_derive", "pth_matrix_mul", "pth_gltf_local_matrix",
     "pth_alias_build", "pth_camera_make", "pth_bvh_build", "pth_bvh_sizes", "pth_bvh_get", "pth_bvh_free",
@@ -228,7 +228,6 @@ def load_library() -> C.CDLL:
         "pt_capture_bounce_rays": (i32, [vp, i32, i32, i32, i32, vp, sz, C.POINTER(sz)]),
         "pt_capture_shadow_rays": (i32, [vp, i32, i32, i32, i32, vp, sz, C.POINTER(sz)]),
         "pt_set_trace_mode": (i32, [vp, i32]),
-        "pt_get_trace_layout": (i32, [vp]),
         "pt_set_texture_filter": (i32, [vp, i32]),
         "pt_film_reduce": (i32, [vp, vp, i32]),
         "pt_rccl_unique_id": (i32, [vp, vp]),

@@ -126,8 +126,6 @@ struct DScene {
     const DNode *nodes;
     const DNode4 *nodes4;         // the same trees collapsed to 4-wide nodes (trace mode 2)
     const uint32_t *inst_root4;   // per instance: reference of its BLAS root in nodes4
-    const DNode4 *flat_nodes4;    // trace mode 4: one 4-wide tree over every instance's triangles in world space (null: not built)
-    const DTri *flat_tris;        // its triangle records: world-space corners, c.y = record in `tris`, c.z = instance, c.w = determinant bound of the triangle test
     const DTri *tris;
     const DInst *insts;
     const DInstFwd *fwd;
@@ -148,7 +146,6 @@ struct DScene {
     uint32_t light_count, material_count, geometry_count;
     uint32_t root_ref;
     uint32_t root_ref4;           // TLAS root in nodes4
-    uint32_t flat_root;           // root reference of the flat tree
     float root_min[3], root_max[3];
     uint32_t max_depth;
     uint32_t any_hit_culls_with_tmax;  // trace mode 1: any-hit searches skip boxes that start beyond the ray's t_max

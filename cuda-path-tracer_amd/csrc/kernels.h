@@ -130,7 +130,7 @@ struct ClosestIO {
 #ifndef PT_QUERY_WAVES_PER_SIMD
 #define PT_QUERY_WAVES_PER_SIMD 4  // the 4-wide variants would otherwise take 134 registers: three waves per SIMD, 15 % slower
 #endif
-template <bool COUNT, int WIDE = 0>
+template <bool COUNT, bool WIDE = false>
 __global__ __launch_bounds__(64, PT_QUERY_WAVES_PER_SIMD) void k_trace_closest(DScene S, const pt_ray *rays, uint32_t n, pt_hit *hits, uint32_t *cursors, uint32_t cursor_count,
                                                       uint2 *spill, uint32_t spill_stride, DevStats *stats, TraceCounters *counters) {
     LaneEvents ev;
@@ -167,7 +167,7 @@ struct AnyIO {
     PTD void finish() const {}
 };
 
-template <int WIDE = 0, bool COUNT = false>
+template <bool WIDE = false, bool COUNT = false>
 __global__ __launch_bounds__(64) void k_trace_any(DScene S, const pt_ray *rays, uint32_t n, uint8_t *occluded, uint32_t *cursors, uint32_t cursor_count,
                                                   uint2 *spill, uint32_t spill_stride, DevStats *stats, TraceCounters *counters) {
     LaneEvents ev;
@@ -394,7 +394,7 @@ struct ExtendIO {
 #ifndef PT_EXTEND_WAVES_PER_SIMD
 #define PT_EXTEND_WAVES_PER_SIMD 4
 #endif
-template <int WIDE = 0>
+template <bool WIDE = false>
 __global__ __launch_bounds__(64, PT_EXTEND_WAVES_PER_SIMD) void k_extend(DScene S, PathState P, BounceCounters *cnt, int bounce, int width, int height, uint2 *spill,
                                                uint32_t spill_stride, DevStats *stats) {
     BounceCounters *bc = cnt + bounce;
@@ -784,7 +784,7 @@ struct ShadowIO {
 #ifndef PT_SHADOW_WAVES_PER_SIMD
 #define PT_SHADOW_WAVES_PER_SIMD 4
 #endif
-template <int WIDE = 0>
+template <bool WIDE = false>
 __global__ __launch_bounds__(64, PT_SHADOW_WAVES_PER_SIMD) void k_shadow(DScene S, PathState P, BounceCounters *cnt, int bounce, uint2 *spill,
                                                uint32_t spill_stride, DevStats *stats) {
     BounceCounters *bc = cnt + bounce;

@@ -17,7 +17,6 @@
 #include "debug_view.h"
 #include "bvh_build.h"
 #include "wide_bvh.h"
-#include "flat_bvh.h"
 #ifndef PT_WAVES_PER_CU
 #define PT_WAVES_PER_CU 16  // persistent waves per CU (4 per SIMD) of a ray query
 #endif
@@ -141,7 +140,6 @@ struct pt_ctx {
     std::vector<EventPair> free_events;
     pt_stats stats;
     int trace_mode = 0;
-    bool flat_ready = false;  // the uploaded scene has a flat world-space tree (trace mode 4)
     int texture_filter = 0;  // kTexFixedPointWeights | kTexSrgbDecode, applied by the next pt_scene_upload
     bool host_may_block = false;  // set by the synchronous entry points around RunBounces
 };
@@ -360,7 +358,6 @@ void SetNodeChild(DNode &n, int side, const float *mn, const float *mx, uint32_t
 int FreeScene(pt_ctx *ctx) {
     FreeAll(ctx->scene_allocs);
     ctx->scene_ready = false;
-    ctx->flat_ready = false;
     std::memset(&ctx->scene, 0, sizeof(ctx->scene));
     return PT_OK;
 }
@@ -561,22 +558,12 @@ int pt_debug_wave_times(unsigned long long *out, unsigned waves) {
 }
 #endif
 
-// Trace mode 4 searches the flat world-space tree when the uploaded scene has one and behaves like mode 3
-// (4-wide instanced trees, any-hit culling) when it has not.
-static uint32_t AnyHitCulls(int mode) { return ((mode & 1) || mode == 4) ? 1u : 0u; }
-static int TraceLayout(const pt_ctx *ctx) { return ctx->trace_mode == 4 ? (ctx->flat_ready ? 2 : 1) : ((ctx->trace_mode & 2) ? 1 : 0); }
-
 int pt_set_trace_mode(pt_ctx *ctx, int mode) {
     if (!ctx) return PT_ERR_INVALID;
-    if (mode < 0 || mode > 4) return Fail(ctx, PT_ERR_INVALID, "trace mode %d (bit 0: any-hit culls boxes with t_max, bit 1: 4-wide BVH; 4: one world-space tree)", mode);
+    if (mode < 0 || mode > 3) return Fail(ctx, PT_ERR_INVALID, "trace mode %d (bit 0: any-hit culls boxes with t_max, bit 1: 4-wide BVH)", mode);
     ctx->trace_mode = mode;
-    ctx->scene.any_hit_culls_with_tmax = AnyHitCulls(mode);
+    ctx->scene.any_hit_culls_with_tmax = (mode & 1) ? 1u : 0u;
     return PT_OK;
-}
-
-int pt_get_trace_layout(pt_ctx *ctx) {
-    if (!ctx) return PT_ERR_INVALID;
-    return TraceLayout(ctx);
 }
 
 int pt_set_texture_filter(pt_ctx *ctx, int options) {
@@ -815,42 +802,6 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
                           __builtin_bit_cast(float, uint32_t(g.triangle_sampler_index)), __builtin_bit_cast(float, uint32_t(g.material_id)));
     }
 
-    // ---- trace mode 4: every instance's triangles in world space under one tree (flat_bvh.h)
-    ptw::FlatScene flat;
-    {
-        uint64_t flat_count = 0;
-        for (uint32_t i = 0; i < d->geometry_count; ++i) flat_count += d->blases[d->geometries[i].blas_index].node_count > 0 ? d->blases[d->geometries[i].blas_index].index_count : 0u;
-        if (!getenv("PTAMD_NO_FLAT_TREE") && ptw::FlatPolicy(flat_count, tris.size())) {
-            std::vector<DTri> world;
-            world.reserve(size_t(flat_count));
-            for (uint32_t i = 0; i < d->geometry_count; ++i) {
-                const pt_blas &blas = d->blases[d->geometries[i].blas_index];
-                if (blas.node_count == 0) continue;
-                const DInstFwd &f = fwd[i];
-                const float Tm[12] = {f.t0.x, f.t0.y, f.t0.z, f.t0.w, f.t1.x, f.t1.y, f.t1.z, f.t1.w, f.t2.x, f.t2.y, f.t2.z, f.t2.w};
-                // The reference rejects a triangle whose determinant, computed in object space, is below 1e-9
-                // (math/intersection.h:44-46); that determinant is the world-space one times the volume change
-                // of world -> object, so the same bound in world space is 1e-9 * |det(object -> world)|.
-                const double det = double(Tm[0]) * (double(Tm[4]) * Tm[8] - double(Tm[5]) * Tm[7]) - double(Tm[3]) * (double(Tm[1]) * Tm[8] - double(Tm[2]) * Tm[7]) +
-                                   double(Tm[6]) * (double(Tm[1]) * Tm[5] - double(Tm[2]) * Tm[4]);
-                const float det_eps = float(1e-9 * std::fabs(det));
-                for (uint32_t j = blas.first_index; j < blas.first_index + blas.index_count; ++j) {
-                    const DTri &r = tris[j];
-                    const float p[3][3] = {{r.a.x, r.a.y, r.a.z}, {r.a.w, r.b.x, r.b.y}, {r.b.z, r.b.w, r.c.x}};
-                    float q[3][3];
-                    for (int k = 0; k < 3; ++k)
-                        for (int c = 0; c < 3; ++c) q[k][c] = (Tm[c] * p[k][0] + Tm[3 + c] * p[k][1]) + (Tm[6 + c] * p[k][2] + Tm[9 + c]);
-                    DTri w;
-                    w.a = make_float4(q[0][0], q[0][1], q[0][2], q[1][0]);
-                    w.b = make_float4(q[1][1], q[1][2], q[2][0], q[2][1]);
-                    w.c = make_float4(q[2][2], __builtin_bit_cast(float, j), __builtin_bit_cast(float, i), det_eps);
-                    world.push_back(w);
-                }
-            }
-            flat = ptw::BuildFlatScene(world);
-        }
-    }
-
     // ---- materials, textures, images
     std::vector<DMaterial> mats(d->material_count);
     for (uint32_t i = 0; i < d->material_count; ++i) {
@@ -1024,16 +975,6 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
     if (nodes4.empty()) nodes4.emplace_back();
     UP(nodes4, nodes4);
     UP(inst_root4, inst_root4);
-    S.flat_nodes4 = nullptr;
-    S.flat_tris = nullptr;
-    S.flat_root = kNoRef;
-    ctx->flat_ready = false;
-    if (!flat.nodes4.empty()) {
-        UP(flat_nodes4, flat.nodes4);
-        UP(flat_tris, flat.tris);
-        S.flat_root = flat.root;
-        ctx->flat_ready = true;
-    }
     UP(tris, tris);
     UP(insts, insts);
     UP(fwd, fwd);
@@ -1064,7 +1005,7 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
         S.root_max[a] = d->tlas_nodes[0].max[a];
     }
     S.max_depth = d->max_depth;
-    S.any_hit_culls_with_tmax = AnyHitCulls(ctx->trace_mode);
+    S.any_hit_culls_with_tmax = (ctx->trace_mode & 1) ? 1u : 0u;
     S.total_light_power = d->total_light_power;
     FillCamera(S.camera, d->camera);
     ctx->scene_ready = true;
@@ -1224,7 +1165,7 @@ static int RunBounces(pt_ctx *ctx, pt_ctx::Lane &l, hipStream_t stream, int widt
         hipLaunchKernelGGL(k_generate, dim3(tiles), dim3(kWave), 0, stream, S, P, l.counters, iteration, width, height);
     }
     const dim3 block(kWave);
-    const int layout = TraceLayout(ctx);
+    const bool wide = (ctx->trace_mode & 2) != 0;
     const dim3 grid_extend(ctx->render_blocks[0]), grid_shade(ctx->render_blocks[1]), grid_shadow(ctx->render_blocks[2]);
     ctx->last_render_bounces = bounces;
     for (int b = 0; b < bounces; ++b) {
@@ -1232,9 +1173,8 @@ static int RunBounces(pt_ctx *ctx, pt_ctx::Lane &l, hipStream_t stream, int widt
         if (last && !shade_last) break;
         {
             ScopedEvent ev(timed ? ctx : nullptr, EV_CLOSEST);
-            if (layout == 2) hipLaunchKernelGGL(k_extend<2>, grid_extend, block, 0, stream, S, P, l.counters, b, width, height, l.spill, ctx->spill_stride, ctx->dev_stats);
-            else if (layout == 1) hipLaunchKernelGGL(k_extend<1>, grid_extend, block, 0, stream, S, P, l.counters, b, width, height, l.spill, ctx->spill_stride, ctx->dev_stats);
-            else hipLaunchKernelGGL(k_extend<0>, grid_extend, block, 0, stream, S, P, l.counters, b, width, height, l.spill, ctx->spill_stride, ctx->dev_stats);
+            if (wide) hipLaunchKernelGGL(k_extend<true>, grid_extend, block, 0, stream, S, P, l.counters, b, width, height, l.spill, ctx->spill_stride, ctx->dev_stats);
+            else hipLaunchKernelGGL(k_extend<false>, grid_extend, block, 0, stream, S, P, l.counters, b, width, height, l.spill, ctx->spill_stride, ctx->dev_stats);
         }
         {
             ScopedEvent ev(timed ? ctx : nullptr, EV_SHADE);
@@ -1242,9 +1182,8 @@ static int RunBounces(pt_ctx *ctx, pt_ctx::Lane &l, hipStream_t stream, int widt
         }
         {
             ScopedEvent ev(timed ? ctx : nullptr, EV_ANY);
-            if (layout == 2) hipLaunchKernelGGL(k_shadow<2>, grid_shadow, block, 0, stream, S, P, l.counters, b, l.spill, ctx->spill_stride, ctx->dev_stats);
-            else if (layout == 1) hipLaunchKernelGGL(k_shadow<1>, grid_shadow, block, 0, stream, S, P, l.counters, b, l.spill, ctx->spill_stride, ctx->dev_stats);
-            else hipLaunchKernelGGL(k_shadow<0>, grid_shadow, block, 0, stream, S, P, l.counters, b, l.spill, ctx->spill_stride, ctx->dev_stats);
+            if (wide) hipLaunchKernelGGL(k_shadow<true>, grid_shadow, block, 0, stream, S, P, l.counters, b, l.spill, ctx->spill_stride, ctx->dev_stats);
+            else hipLaunchKernelGGL(k_shadow<false>, grid_shadow, block, 0, stream, S, P, l.counters, b, l.spill, ctx->spill_stride, ctx->dev_stats);
         }
         // Long depth limits: stop launching once the extension queue has drained.  Only a call that blocks
         // the host anyway (pt_render, the ray captures) reads the counter back for that; an asynchronous
@@ -1549,15 +1488,11 @@ int pt_trace_closest(pt_ctx *ctx, const pt_ray *rays, size_t n, pt_hit *hits) {
     const uint32_t blocks = uint32_t(std::min<size_t>(ctx->grid_blocks, (n + kWave - 1) / kWave));
     {
         ScopedEvent ev(ctx, EV_CLOSEST);
-        const int layout = TraceLayout(ctx);
-        if (layout == 2)
-            hipLaunchKernelGGL((k_trace_closest<false, 2>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors,
-                               ctx->lane[0].spill, ctx->spill_stride, ctx->dev_stats, static_cast<TraceCounters *>(nullptr));
-        else if (layout == 1)
-            hipLaunchKernelGGL((k_trace_closest<false, 1>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors,
+        if (ctx->trace_mode & 2)
+            hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors,
                                ctx->lane[0].spill, ctx->spill_stride, ctx->dev_stats, static_cast<TraceCounters *>(nullptr));
         else
-            hipLaunchKernelGGL((k_trace_closest<false, 0>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors,
+            hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors,
                                ctx->lane[0].spill, ctx->spill_stride, ctx->dev_stats, static_cast<TraceCounters *>(nullptr));
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -1580,15 +1515,11 @@ int pt_trace_closest_static(pt_ctx *ctx, const pt_ray *rays, size_t n, pt_hit *h
     // cursors and counters start at zero; the spill area is written before it is read
     HIP_TRY(ctx, hipMemsetAsync(base, 0, kStaticSpillOffset, ctx->stream));
     const uint32_t blocks = uint32_t(std::min<size_t>(std::min<uint32_t>(ctx->grid_blocks, kStaticWaves), (n + kWave - 1) / kWave));
-    const int layout = TraceLayout(ctx);
-    if (layout == 2)
-        hipLaunchKernelGGL((k_trace_closest<false, 2>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, cursors, ctx->query_cursors, spill,
-                           kStaticWaves * uint32_t(kWave), stats, static_cast<TraceCounters *>(nullptr));
-    else if (layout == 1)
-        hipLaunchKernelGGL((k_trace_closest<false, 1>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, cursors, ctx->query_cursors, spill,
+    if (ctx->trace_mode & 2)
+        hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, cursors, ctx->query_cursors, spill,
                            kStaticWaves * uint32_t(kWave), stats, static_cast<TraceCounters *>(nullptr));
     else
-        hipLaunchKernelGGL((k_trace_closest<false, 0>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, cursors, ctx->query_cursors, spill,
+        hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, cursors, ctx->query_cursors, spill,
                            kStaticWaves * uint32_t(kWave), stats, static_cast<TraceCounters *>(nullptr));
     HIP_TRY(ctx, hipGetLastError());
     return PT_OK;
@@ -1602,18 +1533,16 @@ static int TraceAny(pt_ctx *ctx, const pt_ray *rays, size_t n, uint8_t *occluded
     HIP_TRY(ctx, hipMemsetAsync(ctx->cursor, 0, size_t(ctx->query_cursors) * kCursorStride * sizeof(uint32_t), ctx->stream));
     const uint32_t blocks = uint32_t(std::min<size_t>(ctx->grid_blocks, (n + kWave - 1) / kWave));
     TraceCounters *ctr = reinterpret_cast<TraceCounters *>(counters4);
-    const int layout = TraceLayout(ctx);
+    const bool wide = (ctx->trace_mode & 2) != 0;
 #define PT_LAUNCH_ANY(W, C)                                                                                                                     \
     hipLaunchKernelGGL((k_trace_any<W, C>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), occluded, ctx->cursor, \
                        ctx->query_cursors, ctx->lane[0].spill, ctx->spill_stride, ctx->dev_stats, ctr)
     {
         ScopedEvent ev(ctx, EV_ANY);
-        if (layout == 2 && ctr) PT_LAUNCH_ANY(2, true);
-        else if (layout == 2) PT_LAUNCH_ANY(2, false);
-        else if (layout == 1 && ctr) PT_LAUNCH_ANY(1, true);
-        else if (layout == 1) PT_LAUNCH_ANY(1, false);
-        else if (ctr) PT_LAUNCH_ANY(0, true);
-        else PT_LAUNCH_ANY(0, false);
+        if (wide && ctr) PT_LAUNCH_ANY(true, true);
+        else if (wide) PT_LAUNCH_ANY(true, false);
+        else if (ctr) PT_LAUNCH_ANY(false, true);
+        else PT_LAUNCH_ANY(false, false);
     }
 #undef PT_LAUNCH_ANY
     HIP_TRY(ctx, hipGetLastError());
@@ -1648,15 +1577,11 @@ int pt_trace_closest_counted(pt_ctx *ctx, const pt_ray *rays, size_t n, pt_hit *
     HIP_TRY(ctx, Join(ctx));  // lane 0's spill area is shared with render passes
     HIP_TRY(ctx, hipMemsetAsync(ctx->cursor, 0, size_t(ctx->query_cursors) * kCursorStride * sizeof(uint32_t), ctx->stream));
     const uint32_t blocks = uint32_t(std::min<size_t>(ctx->grid_blocks, (n + kWave - 1) / kWave));
-    const int layout = TraceLayout(ctx);
-    if (layout == 2)
-        hipLaunchKernelGGL((k_trace_closest<true, 2>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors, ctx->lane[0].spill,
-                           ctx->spill_stride, ctx->dev_stats, reinterpret_cast<TraceCounters *>(counters4));
-    else if (layout == 1)
-        hipLaunchKernelGGL((k_trace_closest<true, 1>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors, ctx->lane[0].spill,
+    if (ctx->trace_mode & 2)
+        hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors, ctx->lane[0].spill,
                            ctx->spill_stride, ctx->dev_stats, reinterpret_cast<TraceCounters *>(counters4));
     else
-        hipLaunchKernelGGL((k_trace_closest<true, 0>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors, ctx->lane[0].spill,
+        hipLaunchKernelGGL((k_trace_closest<true, false>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors, ctx->lane[0].spill,
                            ctx->spill_stride, ctx->dev_stats, reinterpret_cast<TraceCounters *>(counters4));
     HIP_TRY(ctx, hipGetLastError());
     return PT_OK;

@@ -79,74 +79,6 @@ __device__ unsigned long long g_trace_stamps[8];
 #define PT_TSTAMP_NOWAIT(k) do { } while (0)
 #endif
 
-// One 4-wide node: four slab tests with the reference's arithmetic and acceptance rule
-// (math/intersection.h:9-35) on the boxes stored in the node; the children that are hit are ordered by
-// entry distance, the nearest becomes `cur` and the others are pushed, farthest first.
-PTD void wide_order(uint32_t &ka, uint32_t &ra, uint32_t &kb, uint32_t &rb) {
-    const bool swap = kb < ka;
-    const uint32_t lo = swap ? kb : ka, hi = swap ? ka : kb;
-    const uint32_t rlo = swap ? rb : ra, rhi = swap ? ra : rb;
-    ka = lo; kb = hi; ra = rlo; rb = rhi;
-}
-PTD float wide_comp(const float4 &v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
-template <int DEPTH, class STK>
-PTD void wide_visit(const STK &stk, LaneEvents &ev, const float4 (&q)[7], const V3 &co, const V3 &ci, float cbest, uint32_t &cur, int &sp) {
-    constexpr uint32_t kMiss = 0x7F800000u;  // +inf: sorts behind every hit
-    uint32_t key[4], ref[4] = {as_u(q[6].x), as_u(q[6].y), as_u(q[6].z), as_u(q[6].w)};
-    int n = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float tn;
-        const bool hit = slab(co, ci, wide_comp(q[0], k), wide_comp(q[2], k), wide_comp(q[4], k), wide_comp(q[1], k), wide_comp(q[3], k), wide_comp(q[5], k), cbest, tn);
-        n += hit ? 1 : 0;
-        // the entry distance, clamped at the origin (as an integer: the bits of a negative float are a
-        // negative integer) and rounded down to make room for the slot number that makes the keys distinct
-        const int bits = int(as_u(tn));
-        key[k] = hit ? ((uint32_t(bits < 0 ? 0 : bits) & ~3u) | uint32_t(k)) : (kMiss | uint32_t(k));
-    }
-#ifdef PT_EXP_DOUBLE_VALU  // experiment: the four slab tests are evaluated a second time on an opaque copy of the ray
-    {
-        V3 co2 = co;
-        asm volatile("" : "+v"(co2.x), "+v"(co2.y), "+v"(co2.z));
-        int n2 = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float tn;
-            n2 += slab(co2, ci, wide_comp(q[0], k), wide_comp(q[2], k), wide_comp(q[4], k), wide_comp(q[1], k), wide_comp(q[3], k), wide_comp(q[5], k), cbest, tn) ? 1 : 0;
-            asm volatile("" ::"v"(tn));
-        }
-        asm volatile("" ::"v"(n2));
-    }
-#endif
-    wide_order(key[0], ref[0], key[1], ref[1]);
-    wide_order(key[2], ref[2], key[3], ref[3]);
-    wide_order(key[0], ref[0], key[2], ref[2]);
-    wide_order(key[1], ref[1], key[3], ref[3]);
-    wide_order(key[1], ref[1], key[2], ref[2]);
-    cur = n > 0 ? ref[0] : kNoRef;
-    // Usual case, decided for the wave: every lane has room for three more entries in the LDS part
-    // of its stack.  Then all three candidates are stored without a branch: child j of the sorted
-    // list belongs at sp + n - 1 - j, and the ones that were not hit land above the new top.
-    const bool rare = sp + 3 >= DEPTH;
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) == 0, 1)) {
-#pragma unroll
-        for (int j = 1; j < 4; ++j) stk.lds[(sp + ((n - 1 - j) & 3)) * kWave] = ((unsigned long long)key[j] << 32) | ref[j];
-        sp += n > 1 ? n - 1 : 0;
-        return;
-    }
-#pragma unroll
-    for (int j = 3; j >= 1; --j) {
-        if (j < n) {
-            if (sp < DEPTH + kSpillDepth) {
-                stack_store(stk, sp, ref[j], as_f(key[j]), ev);
-                ++sp;
-            } else {
-                ev.drops++;  // the physical stack is full: the subtree is lost (counted in pt_stats.stack_drops)
-            }
-        }
-    }
-}
-
 // WIDE (trace modes 2 and 3) walks 4-wide nodes (DNode4) instead of the binary ones: half as many
 // dependent node visits, one 128-byte line for four children.  The boxes are the reference's and are
 // tested with its arithmetic, so a box is entered here exactly when its own test passes in the binary
@@ -330,14 +262,63 @@ struct Traversal {
         }
     }
 
-    // One 4-wide node (trace modes 2 and 3): wide_visit() on the ray in its current space.
+    // One 4-wide node (trace modes 2 and 3): four slab tests with the reference's arithmetic and
+    // acceptance rule (math/intersection.h:9-35) on the reference's own boxes, so each box decides as
+    // it does in the binary tree; the children that are hit are ordered by entry distance, the nearest
+    // is visited next and the others are pushed, farthest first.
+    static PTD void order(uint32_t &ka, uint32_t &ra, uint32_t &kb, uint32_t &rb) {
+        const bool swap = kb < ka;
+        const uint32_t lo = swap ? kb : ka, hi = swap ? ka : kb;
+        const uint32_t rlo = swap ? rb : ra, rhi = swap ? ra : rb;
+        ka = lo; kb = hi; ra = rlo; rb = rhi;
+    }
+    static PTD float comp(const float4 &v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
     template <class STK>
     PTD void op_interior4(const STK &stk, LaneEvents &ev, const float4 (&q)[7]) {
         if (COUNT) {
             ctr.interior++;
             if (!in_blas) tlas_interior++;
         }
-        wide_visit<DEPTH>(stk, ev, q, co, ci, cbest, cur, sp);
+        constexpr uint32_t kMiss = 0x7F800000u;  // +inf: sorts behind every hit
+        uint32_t key[4], ref[4] = {as_u(q[6].x), as_u(q[6].y), as_u(q[6].z), as_u(q[6].w)};
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float tn;
+            const bool hit = slab(co, ci, comp(q[0], k), comp(q[2], k), comp(q[4], k), comp(q[1], k), comp(q[3], k), comp(q[5], k), cbest, tn);
+            n += hit ? 1 : 0;
+            // the entry distance, clamped at the origin (as an integer: the bits of a negative float are a
+            // negative integer) and rounded down to make room for the slot number that makes the keys distinct
+            const int bits = int(as_u(tn));
+            key[k] = hit ? ((uint32_t(bits < 0 ? 0 : bits) & ~3u) | uint32_t(k)) : (kMiss | uint32_t(k));
+        }
+        order(key[0], ref[0], key[1], ref[1]);
+        order(key[2], ref[2], key[3], ref[3]);
+        order(key[0], ref[0], key[2], ref[2]);
+        order(key[1], ref[1], key[3], ref[3]);
+        order(key[1], ref[1], key[2], ref[2]);
+        cur = n > 0 ? ref[0] : kNoRef;
+        // Usual case, decided for the wave: every lane has room for three more entries in the LDS part
+        // of its stack.  Then all three candidates are stored without a branch: child j of the sorted
+        // list belongs at sp + n - 1 - j, and the ones that were not hit land above the new top.
+        const bool rare = sp + 3 >= DEPTH;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) == 0, 1)) {
+#pragma unroll
+            for (int j = 1; j < 4; ++j) stk.lds[(sp + ((n - 1 - j) & 3)) * kWave] = ((unsigned long long)key[j] << 32) | ref[j];
+            sp += n > 1 ? n - 1 : 0;
+            return;
+        }
+#pragma unroll
+        for (int j = 3; j >= 1; --j) {
+            if (j < n) {
+                if (sp < DEPTH + kSpillDepth) {
+                    stack_store(stk, sp, ref[j], as_f(key[j]), ev);
+                    ++sp;
+                } else {
+                    ev.drops++;  // the physical stack is full: the subtree is lost (counted in pt_stats.stack_drops)
+                }
+            }
+        }
     }
 
     // TLAS leaf: enter the instance (kernel/intersection.h:183-188, :37-50).
@@ -512,178 +493,6 @@ struct Traversal {
     }
 };
 
-// Trace mode 4: one tree over the whole scene.  Every instance's triangles are carried into world space
-// when the scene is uploaded and a 4-wide BVH is built over all of them (flat_bvh.h), so a ray needs no
-// instance enter / exit and no per-instance restart; it is searched in world space with the reference's
-// slab and triangle tests (math/intersection.h:9-71).  What the reference computes in the instance's object
-// space - whether the triangle is hit, its barycentrics, the distance recomputed from the hit point
-// (kernel/intersection.h:63-112, :139-149) - is evaluated once per ray for the winner, from the instance's
-// own records, so distance and barycentrics are the reference's bits whenever the same triangle wins.  The
-// winner can differ from the reference's where two triangles are within rounding of the same distance, or
-// where the world-space and object-space tests disagree about a ray that grazes an edge.
-//
-// Any-hit queries stop at the first accepted triangle farther than kAnyHitSettles; a nearer one counts only
-// if the object-space test accepts it too and the recomputed distance is not negative (the reference
-// reports such a ray as unoccluded, see Traversal::op_triangle).  Boxes are culled with t_max and the
-// margin of trace modes 1 / 3.
-template <int MODE, bool COUNT, int DEPTH>
-struct FlatTraversal {
-    V3 o, d, iw;
-    float t_max;
-    float best;    // closest hit: the winner's distance once finished (FLT_MAX: none)
-    float cbest;   // culling bound: the nearest world-space distance so far (closest hit), t_max with its margin (any hit)
-    uint32_t l_rec, l_orec, l_inst;  // winner so far: record in the flat array, record in the instance's mesh, instance
-    int sp;
-    uint32_t cur;
-    uint32_t tri_next, tri_left;
-    HitRec hit;
-    bool found;
-    bool in_blas;  // unused: the scheduler's idle state sets it
-    int base;      // unused, likewise
-    TraceCounters ctr;
-
-    PTD bool begin(const DScene &S, V3 origin, V3 dir, float tmax) {
-        o = origin;
-        d = dir;
-        t_max = tmax;
-        hit.t = -1.0f;
-        hit.u = hit.v = 0.0f;
-        hit.rec = 0;
-        hit.inst = -1;
-        hit.prim = hit.mat = hit.type = 0xFFFFFFFFu;
-        found = false;
-        if (COUNT) ctr = TraceCounters{0, 0, 0, 0};
-        iw = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-        float t;
-        if (!slab(o, iw, S.root_min[0], S.root_min[1], S.root_min[2], S.root_max[0], S.root_max[1], S.root_max[2], t_max, t)) return false;
-        best = FLT_MAX;
-        cbest = MODE == MODE_ANY ? t_max + fabsf(t_max) * PT_ANY_CULL_MARGIN : FLT_MAX;
-        l_rec = l_orec = l_inst = 0xFFFFFFFFu;
-        sp = 0;
-        cur = S.flat_root;
-        tri_next = tri_left = 0;
-        return true;
-    }
-    PTD bool closest_valid() const { return !(best < 0.0f || best == FLT_MAX); }
-    PTD bool wants_interior() const { return cur < kNoRef; }
-    PTD bool wants_enter() const { return false; }
-    PTD bool wants_triangle() const { return cur > kNoRef; }
-    PTD bool may_pop() const { return cur == kNoRef && sp != 0; }
-    PTD bool wants_pop() const { return may_pop() && sp <= DEPTH; }
-    PTD bool wants_deep_pop() const { return may_pop() && sp > DEPTH; }
-    PTD bool wants_level() const { return cur == kNoRef && sp == 0; }
-    PTD void set_leaf_aside() {}
-    template <class STK>
-    PTD void pop(const STK &stk) {
-        --sp;
-        const unsigned long long v = stk.lds[sp * kWave];
-        if (MODE == MODE_ANY || as_f(uint32_t(v >> 32)) < cbest) cur = uint32_t(v);
-    }
-    template <class STK>
-    PTD void deep_pop(const STK &stk) {
-        --sp;
-        const uint2 e = stack_load(stk, sp);
-        if (MODE == MODE_ANY || as_f(e.y) < cbest) cur = e.x;
-    }
-    template <class STK>
-    PTD void op_interior4(const STK &stk, LaneEvents &ev, const float4 (&q)[7]) {
-        if (COUNT) ctr.interior++;
-        wide_visit<DEPTH>(stk, ev, q, o, iw, cbest, cur, sp);
-    }
-    template <class STK>
-    PTD void op_interior(const STK &, LaneEvents &, float4, float4, float4, float4) {}
-    PTD void op_enter(const DScene &) {}
-
-    // The reference's own evaluation of triangle `orec` of instance `inst` for this ray: the test in object
-    // space and the distance recomputed in world space.  False when the object-space test rejects it.
-    PTD bool reference_hit(const DScene &S, uint32_t orec, uint32_t inst, float &t, float &u, float &v, uint32_t &prim, uint32_t &mat, uint32_t &type) const {
-        const float4 *ip = reinterpret_cast<const float4 *>(S.insts + inst);
-        const float4 *tp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(S.tris) + size_t(orec) * sizeof(DTri));
-        const float4 *fp = reinterpret_cast<const float4 *>(S.fwd + inst);
-        DInst in;
-        in.a = ip[0];
-        in.b = ip[1];
-        in.c = ip[2];
-        in.d = ip[3];
-        const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-        const float4 f0 = fp[0], f1 = fp[1], f2 = fp[2];
-        const M34 inv = load_inv(in);
-        const V3 co = xform(inv, o, 1.0f), cd = xform(inv, d, 0.0f);
-        prim = as_u(tc.y);
-        mat = as_u(in.d.y);
-        type = as_u(in.d.z);
-        float to;
-        if (!tri_test(co, cd, ta, tb, tc, t_max, to, u, v)) return false;
-        const V3 p0 = mk3(ta.x, ta.y, ta.z), p1 = mk3(ta.w, tb.x, tb.y), p2 = mk3(tb.z, tb.w, tc.x);
-        const float w = 1.0f - u - v;
-        const V3 lp = w * p0 + u * p1 + v * p2;
-        t = dot(xform(load_m34(f0, f1, f2), lp, 1.0f) - o, d);
-        return true;
-    }
-
-    PTD bool op_triangle(const DScene &S) {
-        if (tri_left == 0) {
-            if (COUNT) ctr.blas_leaves++;
-            tri_next = cur & 0x0FFFFFFFu;
-            tri_left = ((cur >> 28) & 7u) + 1u;  // the flat builder makes no leaf of more than 7 triangles
-        }
-        if (COUNT) ctr.tris++;
-        const float4 *tp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(S.flat_tris) + size_t(tri_next) * sizeof(DTri));
-        const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-        float t, u, v;
-        const bool ok = tri_test(o, d, ta, tb, tc, t_max, t, u, v, tc.w);
-        if (MODE == MODE_ANY) {
-            if (ok) {
-                if (t > kAnyHitSettles) {
-                    found = true;
-                    return true;
-                }
-                float wt, ru, rv;
-                uint32_t prim, mat, type;
-                if (reference_hit(S, as_u(tc.y), as_u(tc.z), wt, ru, rv, prim, mat, type) && !(wt < 0.0f)) {
-                    found = true;
-                    return true;
-                }
-            }
-        } else if (ok && t < cbest) {
-            cbest = t;
-            l_rec = tri_next;
-            l_orec = as_u(tc.y);
-            l_inst = as_u(tc.z);
-        }
-        ++tri_next;
-        --tri_left;
-        if (tri_left == 0) cur = kNoRef;
-        return false;
-    }
-
-    // The search is over: the winner, if any, is reported with the reference's distance and barycentrics.
-    template <bool EXACT_T = true>
-    PTD bool op_level(const DScene &S) {
-        if (MODE == MODE_CLOSEST && l_rec != 0xFFFFFFFFu) {
-            float t, u, v;
-            uint32_t prim, mat, type;
-            if (!reference_hit(S, l_orec, l_inst, t, u, v, prim, mat, type)) {
-                // the object-space test rejects what the world-space test accepted (a ray within rounding of
-                // an edge): the hit stands with its world-space values
-                const float4 *tp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(S.flat_tris) + size_t(l_rec) * sizeof(DTri));
-                const float4 tc = tp[2];
-                tri_test(o, d, tp[0], tp[1], tc, t_max, t, u, v, tc.w);
-            }
-            best = t;
-            hit.t = t;
-            hit.u = u;
-            hit.v = v;
-            hit.rec = l_orec;
-            hit.inst = int(l_inst);
-            hit.prim = prim;
-            hit.mat = mat;
-            hit.type = type;
-        }
-        return true;
-    }
-};
-
 // Streams `n` rays through a persistent wave: the wave pulls chunks of ray indices (fetch_rays)
 // from a global cursor, and every lane that finishes its ray takes the next index of the
 // chunk while its neighbours keep traversing (refill happens once at least kRefillMin lanes
@@ -756,16 +565,9 @@ PTD bool fetch_rays(const WorkFeed &feed, uint32_t n, uint32_t &dry, uint32_t &b
     return true;
 }
 
-// LAYOUT: 0 the reference's binary trees, 1 the same trees collapsed to 4-wide nodes, 2 one 4-wide tree over
-// the whole scene in world space (FlatTraversal).
-template <int LAYOUT, class T0, class T2>
-struct PickTraversal { typedef T0 type; };
-template <class T0, class T2>
-struct PickTraversal<2, T0, T2> { typedef T2 type; };
-template <int MODE, bool COUNT, int LAYOUT = 0, class IO, class STK>
+template <int MODE, bool COUNT, bool WIDE = false, class IO, class STK>
 PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed, const STK &stk, LaneEvents &ev) {
-    constexpr bool WIDE = LAYOUT != 0;
-    typename PickTraversal<LAYOUT, Traversal<MODE, COUNT, STK::kDepth, LAYOUT == 1>, FlatTraversal<MODE, COUNT, STK::kDepth>>::type tr;
+    Traversal<MODE, COUNT, STK::kDepth, WIDE> tr;
     tr.cur = kNoRef;
     tr.in_blas = false;
     tr.sp = tr.base = 0;
@@ -778,7 +580,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
     unsigned long long tstamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tstamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstamp_last)::"memory");
 #endif
-    const char *node_base = LAYOUT == 2 ? reinterpret_cast<const char *>(S.flat_nodes4) : WIDE ? reinterpret_cast<const char *>(S.nodes4) : reinterpret_cast<const char *>(S.nodes);
+    const char *node_base = WIDE ? reinterpret_cast<const char *>(S.nodes4) : reinterpret_cast<const char *>(S.nodes);
     constexpr int kNodeShift = WIDE ? 7 : 6;  // 128-byte wide nodes, 64-byte binary ones
     constexpr int kNodeRegs = WIDE ? 7 : 4;   // 16-byte words of a node that the box tests read
 #if PT_STAGE_RAYS
@@ -886,13 +688,6 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
                 const float4 *np = reinterpret_cast<const float4 *>(node_base + (size_t(tr.cur) << kNodeShift));
 #pragma unroll
                 for (int r = 0; r < kNodeRegs; ++r) nq[r] = np[r];
-#ifdef PT_EXP_DOUBLE_LOAD  // experiment: every node is requested twice (the second request hits the L1)
-#pragma unroll
-                for (int r = 0; r < kNodeRegs; ++r) {
-                    const v4f again = *reinterpret_cast<const volatile v4f *>(np + r);
-                    asm volatile("" ::"v"(again.x), "v"(again.w));
-                }
-#endif
             }
 #if !PT_POP_FIRST
             if (active && tr.wants_pop()) {

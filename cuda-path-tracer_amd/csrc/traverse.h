@@ -153,15 +153,13 @@ PTD bool slab(V3 o, V3 inv, float minx, float miny, float minz, float maxx, floa
     return (tfar >= tnear) && (tnear < t_max) && (tfar > 0.0f);
 }
 
-// math/intersection.h:37-71 on a packed triangle record.  `det_eps` is the reference's 1e-9 bound on the
-// determinant; the world-space records of trace mode 4 carry it scaled by their instance's volume change,
-// because the reference applies it to the determinant it computes in object space.
-PTD bool tri_test(V3 o, V3 d, float4 ta, float4 tb, float4 tc, float t_max, float &t_out, float &u_out, float &v_out, float det_eps = 1e-9f) {
+// math/intersection.h:37-71 on a packed triangle record.
+PTD bool tri_test(V3 o, V3 d, float4 ta, float4 tb, float4 tc, float t_max, float &t_out, float &u_out, float &v_out) {
     const V3 v0 = mk3(ta.x, ta.y, ta.z), v1 = mk3(ta.w, tb.x, tb.y), v2 = mk3(tb.z, tb.w, tc.x);
     const V3 edge1 = v1 - v0, edge2 = v2 - v0;
     const V3 p = cross(d, edge2);
     const float a = dot(edge1, p);
-    if (fabsf(a) < det_eps) return false;
+    if (fabsf(a) < 1e-9f) return false;
     const float inv_a = 1.0f / a;
     const V3 tvec = o - v0;
     const float u = dot(tvec, p) * inv_a;

@@ -399,16 +399,8 @@ class Context:
 
     def set_trace_mode(self, mode: int):
         """Two bits. 0 = reference-exact (default); bit 0: any-hit searches skip boxes beyond the ray's
-        t_max; bit 1: 4-wide BVH nodes, rebuilt top level, searches bounded across instances.
-        4 = one world-space tree over the whole scene where the upload built one (trace_layout() == 2)."""
+        t_max; bit 1: 4-wide BVH nodes, rebuilt top level, searches bounded across instances."""
         self._check(self._lib.pt_set_trace_mode(self._h, int(mode)))
-
-    def trace_layout(self) -> int:
-        """0 binary trees, 1 4-wide trees, 2 the flat world-space tree: what the current mode walks."""
-        r = self._lib.pt_get_trace_layout(self._h)
-        if r < 0:
-            self._check(r)
-        return int(r)
 
     def set_texture_filter(self, options: int):
         """Bit 0: bilinear weights with 8 fractional bits (as the CUDA texture unit); bit 1: sRGB decode of

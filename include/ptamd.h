@@ -476,7 +476,7 @@ int pt_capture_bounce_rays(pt_ctx *ctx, int width, int height, int iteration, in
 int pt_capture_shadow_rays(pt_ctx *ctx, int width, int height, int iteration, int bounce,
                            pt_ray *rays_device, size_t capacity, size_t *count);
 
-/* Traversal variant: two independent bits, or 4; 0 (default) answers every query exactly like the reference,
+/* Traversal variant, two independent bits; 0 (default) answers every query exactly like the reference,
  * including what its any-hit search does after the first accepted triangle: it finishes the instance
  * (boxes tested against the latest accepted distance) and reports a hit only if the world-space distance
  * recomputed from the last accepted triangle is not negative (kernel/intersection.h:101-109, :139-149).
@@ -497,22 +497,8 @@ int pt_capture_shadow_rays(pt_ctx *ctx, int width, int height, int iteration, in
  *   the instances visited before.  Every box decides as in the reference; the visiting order differs,
  *   so rays with two triangles at the same distance may report the other one (same t to rounding;
  *   all other rays get bit-identical records), and the 64-entry stack limit of the reference
- *   (utils/stack.h:8-11) is not reproduced: deep trees are traversed completely.
- * Mode 4: one tree over the whole scene.  pt_scene_upload carries every instance's triangles into world
- *   space and builds a 4-wide BVH of this library's own over all of them, when that copy is at most twice
- *   the instanced scene (+ 65 536 triangles) and 2^25 triangles; rays then need no instance enter / exit
- *   (kernel/intersection.h:37-50, :139-149, :183-200) and instances that overlap are not searched one
- *   after the other.  The winner's distance and barycentrics are evaluated once, in its instance's object
- *   space with the reference's arithmetic, so they are the reference's bits whenever the same triangle
- *   wins; another triangle can win where two are within rounding of the same distance or where a ray
- *   grazes an edge.  Any-hit searches follow the rules of bit 0.  Scenes that are not flattened (thousands
- *   of copies of one mesh) are traced as in mode 3; pt_get_trace_layout says which applies.            */
+ *   (utils/stack.h:8-11) is not reproduced: deep trees are traversed completely.                  */
 int pt_set_trace_mode(pt_ctx *ctx, int mode);
-
-/* The layout the current trace mode walks for the uploaded scene: 0 the reference's binary trees, 1 the
- * same trees as 4-wide nodes, 2 the flat world-space tree of trace mode 4.  Replaces nothing in the
- * reference (it has one layout, kernel/device_types.h:130-166).                                        */
-int pt_get_trace_layout(pt_ctx *ctx);
 
 #ifdef __cplusplus
 }
