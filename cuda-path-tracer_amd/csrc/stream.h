@@ -43,6 +43,11 @@
 // child, costs the 4-wide kernel 16 more spilled registers and 12 %.
 #define PT_POP_FIRST 1
 #endif
+// Diagnostic builds that ask which resource the traversal responds to (tools/sensitivity.sh):
+//   -DPT_EXP_DOUBLE_LOAD  every node of the box loop is requested a second time (the repeat hits the L1)
+//   -DPT_EXP_DOUBLE_VALU  the slab tests of a node are evaluated a second time on an opaque copy of the ray
+// Results are unchanged in both.  Measured on the bench's ray batch: the repeated loads cost 50 %, the
+// repeated slab tests (+ 65 % of a 4-wide visit's vector instructions) 15 %.
 #ifndef PT_POSTPONE_LEAVES
 #define PT_POSTPONE_LEAVES 0  // 1: lanes set leaves aside and keep testing boxes (see Traversal::kPostpone)
 #endif
@@ -58,6 +63,11 @@ constexpr float kAnyHitSettles = 1e-2f;
 // stamp first waiting for all outstanding memory operations (so the waits are attributed to the part
 // that issued them).  0 box round: votes + load issue + pop, 1 box round: wait for the node,
 // 2 box round: box tests + push, 3 triangle rounds, 4 enter / level rounds, 5 refill, 6 rounds counted.
+// Diagnostic build only (-DPT_NODE_HIST): visits per node record of the box loop (tools/node_hist.py).
+#ifdef PT_NODE_HIST
+constexpr uint32_t kNodeHistSize = 1u << 20;
+__device__ unsigned int g_node_hist[kNodeHistSize];
+#endif
 #ifdef PT_TRACE_STAMPS
 __device__ unsigned long long g_trace_stamps[8];
 #define PT_TSTAMP(k)                                                                                         \
@@ -209,6 +219,16 @@ struct Traversal {
         float tl, tr;
         const bool hl = slab(co, ci, na.x, na.y, na.z, nb.x, nb.y, nb.z, cbest, tl);
         const bool hr = slab(co, ci, nc.x, nc.y, nc.z, nd.x, nd.y, nd.z, cbest, tr);
+#ifdef PT_EXP_DOUBLE_VALU
+        {
+            V3 co2 = co;
+            asm volatile("" : "+v"(co2.x), "+v"(co2.y), "+v"(co2.z));
+            float t2l, t2r;
+            const bool h2l = slab(co2, ci, na.x, na.y, na.z, nb.x, nb.y, nb.z, cbest, t2l);
+            const bool h2r = slab(co2, ci, nc.x, nc.y, nc.z, nd.x, nd.y, nd.z, cbest, t2r);
+            asm volatile("" ::"v"(t2l), "v"(t2r), "v"(int(h2l) + int(h2r)));
+        }
+#endif
         const uint32_t lref = as_u(na.w), rref = as_u(nb.w);
         const int depth = sp - base;
         const bool both = hl && hr;
@@ -292,6 +312,20 @@ struct Traversal {
             const int bits = int(as_u(tn));
             key[k] = hit ? ((uint32_t(bits < 0 ? 0 : bits) & ~3u) | uint32_t(k)) : (kMiss | uint32_t(k));
         }
+#ifdef PT_EXP_DOUBLE_VALU
+        {
+            V3 co2 = co;
+            asm volatile("" : "+v"(co2.x), "+v"(co2.y), "+v"(co2.z));
+            int n2 = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float tn;
+                n2 += slab(co2, ci, comp(q[0], k), comp(q[2], k), comp(q[4], k), comp(q[1], k), comp(q[3], k), comp(q[5], k), cbest, tn) ? 1 : 0;
+                asm volatile("" ::"v"(tn));
+            }
+            asm volatile("" ::"v"(n2));
+        }
+#endif
         order(key[0], ref[0], key[1], ref[1]);
         order(key[2], ref[2], key[3], ref[3]);
         order(key[0], ref[0], key[2], ref[2]);
@@ -550,8 +584,8 @@ PTD WorkFeed make_feed(uint32_t *cursors, uint32_t groups, uint32_t n) {
 // One work fetch: true and [base, end) when the wave got rays.  `dry` counts the cursors the wave
 // has found empty (wave-uniform; the feed is exhausted once dry == groups).  A fetch probes one
 // cursor, so a wave whose other lanes are still traversing waits for one round trip at most.
-PTD bool fetch_rays(const WorkFeed &feed, uint32_t n, uint32_t &dry, uint32_t &base, uint32_t &end) {
-    const uint32_t g = (blockIdx.x + dry) % feed.groups;
+PTD bool fetch_rays(const WorkFeed &feed, uint32_t wave, uint32_t n, uint32_t &dry, uint32_t &base, uint32_t &end) {
+    const uint32_t g = (wave + dry) % feed.groups;
     uint32_t t = 0;
     if ((threadIdx.x & 63u) == 0) t = atomicAdd(feed.cursors + size_t(g) * kCursorStride, 1u);
     t = __shfl(t, 0, 64);
@@ -583,6 +617,30 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
     const char *node_base = WIDE ? reinterpret_cast<const char *>(S.nodes4) : reinterpret_cast<const char *>(S.nodes);
     constexpr int kNodeShift = WIDE ? 7 : 6;  // 128-byte wide nodes, 64-byte binary ones
     constexpr int kNodeRegs = WIDE ? 7 : 4;   // 16-byte words of a node that the box tests read
+    // A node record comes out of the workgroup's LDS copy when its reference is below the cached count,
+    // through the vector memory pipeline otherwise.
+    auto fetch_node = [&](uint32_t ref, float4(&nq)[kNodeRegs]) {
+        if constexpr (STK::kHot) {
+            if (ref < stk.hot_count) {
+#pragma unroll
+                for (int r = 0; r < kNodeRegs; ++r) {
+                    const v4f t = stk.hot[hot_slot<WIDE ? 8 : 4>(ref, uint32_t(r))];
+                    nq[r] = make_float4(t.x, t.y, t.z, t.w);
+                }
+                return;
+            }
+        }
+        const float4 *np = reinterpret_cast<const float4 *>(node_base + (size_t(ref) << kNodeShift));
+#pragma unroll
+        for (int r = 0; r < kNodeRegs; ++r) nq[r] = np[r];
+#ifdef PT_EXP_DOUBLE_LOAD
+#pragma unroll
+        for (int r = 0; r < kNodeRegs; ++r) {
+            const v4f again = *reinterpret_cast<const volatile v4f *>(np + r);
+            asm volatile("" ::"v"(again.x), "v"(again.w));
+        }
+#endif
+    };
 #if PT_STAGE_RAYS
     // Rays are read 64 at a time, by all lanes together, into the wave's LDS, and handed to lanes as
     // they fall idle: the wave then waits for a gather from path state (thousands of cycles when the
@@ -596,7 +654,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
             for (;;) {
                 if (stage_next == stage_end) {  // restock
                     if (pool_next >= pool_end && !exhausted) {
-                        if (!fetch_rays(feed, n, dry, pool_next, pool_end)) exhausted = dry >= feed.groups;
+                        if (!fetch_rays(feed, stk.wave, n, dry, pool_next, pool_end)) exhausted = dry >= feed.groups;
                     }
                     if (pool_next >= pool_end) break;
                     const uint32_t count = (pool_end - pool_next < uint32_t(kWave)) ? pool_end - pool_next : uint32_t(kWave);
@@ -642,7 +700,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
         if (idle >= kRefillMin || idle == kWave) {
             io.flush();
             if (pool_next >= pool_end && !exhausted) {
-                if (!fetch_rays(feed, n, dry, pool_next, pool_end)) exhausted = dry >= feed.groups;
+                if (!fetch_rays(feed, stk.wave, n, dry, pool_next, pool_end)) exhausted = dry >= feed.groups;
             }
             if (pool_next < pool_end) {
                 const uint32_t prefix = __builtin_amdgcn_mbcnt_hi(uint32_t(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle_mask), 0u));
@@ -684,11 +742,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
             const bool w_int = active && tr.wants_interior();
             const bool go = __builtin_popcountll(int_mask) >= vote_int;
             float4 nq[kNodeRegs];
-            if (go && w_int) {
-                const float4 *np = reinterpret_cast<const float4 *>(node_base + (size_t(tr.cur) << kNodeShift));
-#pragma unroll
-                for (int r = 0; r < kNodeRegs; ++r) nq[r] = np[r];
-            }
+            if (go && w_int) fetch_node(tr.cur, nq);
 #if !PT_POP_FIRST
             if (active && tr.wants_pop()) {
                 PT_PHASE(ev, 3);
@@ -700,6 +754,9 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
             PT_TSTAMP(1);
             if (w_int) {
                 PT_PHASE(ev, 0);
+#ifdef PT_NODE_HIST
+                atomicAdd(&g_node_hist[tr.cur < kNodeHistSize ? tr.cur : kNodeHistSize - 1], 1u);
+#endif
                 if constexpr (WIDE) tr.op_interior4(stk, ev, nq);
                 else tr.op_interior(stk, ev, nq[0], nq[1], nq[2], nq[3]);
             }
@@ -728,10 +785,11 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
         if (n_int == n_max || (drain && n_int > 0)) {  // fewer than PT_VOTE_INT lanes, but still the largest group
             if (w_int) {
                 PT_PHASE(ev, 0);
-                const float4 *np = reinterpret_cast<const float4 *>(node_base + (size_t(tr.cur) << kNodeShift));
+#ifdef PT_NODE_HIST
+                atomicAdd(&g_node_hist[tr.cur < kNodeHistSize ? tr.cur : kNodeHistSize - 1], 1u);
+#endif
                 float4 nq[kNodeRegs];
-#pragma unroll
-                for (int r = 0; r < kNodeRegs; ++r) nq[r] = np[r];
+                fetch_node(tr.cur, nq);
                 if constexpr (WIDE) tr.op_interior4(stk, ev, nq);
                 else tr.op_interior(stk, ev, nq[0], nq[1], nq[2], nq[3]);
             }
