@@ -1534,12 +1534,17 @@ int pt_trace_closest(pt_ctx *ctx, const pt_ray *rays, size_t n, pt_hit *hits) {
     static const bool node_cache = !(getenv("PTAMD_NODE_CACHE") && atoi(getenv("PTAMD_NODE_CACHE")) == 0);
     if (node_cache && ctx->grid_blocks % kCachedWaves == 0) {
         const uint32_t groups = uint32_t(std::min<size_t>(ctx->grid_blocks / kCachedWaves, (n + kCachedWaves * kWave - 1) / (kCachedWaves * kWave)));
+        DScene scene = ctx->scene;
+        if (const char *e = getenv("PTAMD_HOT_LIMIT")) {  // tuning aid: cache fewer records
+            scene.hot2_count = std::min<uint32_t>(scene.hot2_count, uint32_t(atoi(e)));
+            scene.hot4_count = std::min<uint32_t>(scene.hot4_count, uint32_t(atoi(e)));
+        }
         ScopedEvent ev(ctx, EV_CLOSEST);
         if (ctx->trace_mode & 2)
-            hipLaunchKernelGGL((k_trace_closest_cached<true>), dim3(groups), dim3(kCachedWaves * kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors,
+            hipLaunchKernelGGL((k_trace_closest_cached<true>), dim3(groups), dim3(kCachedWaves * kWave), 0, ctx->stream, scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors,
                                ctx->lane[0].spill, ctx->spill_stride, ctx->dev_stats);
         else
-            hipLaunchKernelGGL((k_trace_closest_cached<false>), dim3(groups), dim3(kCachedWaves * kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors,
+            hipLaunchKernelGGL((k_trace_closest_cached<false>), dim3(groups), dim3(kCachedWaves * kWave), 0, ctx->stream, scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors,
                                ctx->lane[0].spill, ctx->spill_stride, ctx->dev_stats);
     } else {
         ScopedEvent ev(ctx, EV_CLOSEST);

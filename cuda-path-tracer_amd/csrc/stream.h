@@ -44,10 +44,10 @@
 #define PT_POP_FIRST 1
 #endif
 // Diagnostic builds that ask which resource the traversal responds to (tools/sensitivity.sh):
-//   -DPT_EXP_DOUBLE_LOAD  every node of the box loop is requested a second time (the repeat hits the L1)
+//   -DPT_EXP_DOUBLE_LOAD  every 16-byte piece of a node of the box loop is requested a second time (one word,
+//                         issued with the node's own loads, used after the box test; the repeats hit the L1)
 //   -DPT_EXP_DOUBLE_VALU  the slab tests of a node are evaluated a second time on an opaque copy of the ray
-// Results are unchanged in both.  Measured on the bench's ray batch: the repeated loads cost 50 %, the
-// repeated slab tests (+ 65 % of a 4-wide visit's vector instructions) 15 %.
+// Results are unchanged in both.
 #ifndef PT_POSTPONE_LEAVES
 #define PT_POSTPONE_LEAVES 0  // 1: lanes set leaves aside and keep testing boxes (see Traversal::kPostpone)
 #endif
@@ -619,6 +619,9 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
     constexpr int kNodeRegs = WIDE ? 7 : 4;   // 16-byte words of a node that the box tests read
     // A node record comes out of the workgroup's LDS copy when its reference is below the cached count,
     // through the vector memory pipeline otherwise.
+#ifdef PT_EXP_DOUBLE_LOAD
+    float dup_word[kNodeRegs];
+#endif
     auto fetch_node = [&](uint32_t ref, float4(&nq)[kNodeRegs]) {
         if constexpr (STK::kHot) {
             if (ref < stk.hot_count) {
@@ -634,11 +637,10 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
 #pragma unroll
         for (int r = 0; r < kNodeRegs; ++r) nq[r] = np[r];
 #ifdef PT_EXP_DOUBLE_LOAD
+        // one more request per 16-byte piece, issued with the others and consumed only after the node has been
+        // used, so that the round's chain of dependent waits stays what it was
 #pragma unroll
-        for (int r = 0; r < kNodeRegs; ++r) {
-            const v4f again = *reinterpret_cast<const volatile v4f *>(np + r);
-            asm volatile("" ::"v"(again.x), "v"(again.w));
-        }
+        for (int r = 0; r < kNodeRegs; ++r) asm volatile("global_load_dword %0, %1, off offset:4" : "=v"(dup_word[r]) : "v"(np + r));  // a plain cached load the compiler cannot merge
 #endif
     };
 #if PT_STAGE_RAYS
@@ -759,6 +761,10 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
 #endif
                 if constexpr (WIDE) tr.op_interior4(stk, ev, nq);
                 else tr.op_interior(stk, ev, nq[0], nq[1], nq[2], nq[3]);
+#ifdef PT_EXP_DOUBLE_LOAD
+#pragma unroll
+                for (int r = 0; r < kNodeRegs; ++r) asm volatile("s_waitcnt vmcnt(0)" ::"v"(dup_word[r]));
+#endif
             }
             PT_TSTAMP(2);
 #ifdef PT_TRACE_STAMPS
