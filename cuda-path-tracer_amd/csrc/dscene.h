@@ -146,7 +146,6 @@ struct DScene {
     uint32_t light_count, material_count, geometry_count;
     uint32_t root_ref;
     uint32_t root_ref4;           // TLAS root in nodes4
-    uint32_t hot2_count, hot4_count;  // the first records of nodes / nodes4 are the most visited ones (hot_nodes.h): how many the query kernel may cache
     float root_min[3], root_max[3];
     uint32_t max_depth;
     uint32_t any_hit_culls_with_tmax;  // trace mode 1: any-hit searches skip boxes that start beyond the ray's t_max

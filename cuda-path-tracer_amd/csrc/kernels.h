@@ -143,39 +143,6 @@ __global__ __launch_bounds__(64, PT_QUERY_WAVES_PER_SIMD) void k_trace_closest(D
     flush_events(stats, ev);
 }
 
-// The same query with the most visited node records in LDS: one workgroup of 16 waves per compute unit
-// shares a 16 KB copy of the first S.hot2_count / S.hot4_count records (hot_nodes.h puts the records that
-// cover the most surface there), each wave keeps a 14-entry stack and its ray stage behind it - all 160 KB of
-// the unit's LDS.  About half of a bounce ray's node visits are then served by LDS reads instead of the
-// vector memory pipeline, which is the resource this kernel runs out of first.
-constexpr int kCachedWaves = 16;
-constexpr int kCachedDepth = 14;
-constexpr int kHotEntries = 16384 / 8;  // the cache, in the 8-byte units of the LDS array
-static_assert((kHotEntries + kCachedWaves * wave_lds_entries<kCachedDepth>()) * 8 == 160 * 1024, "the workgroup declares the whole LDS of a compute unit");
-template <bool WIDE>
-__global__ __launch_bounds__(kCachedWaves * 64) void k_trace_closest_cached(DScene S, const pt_ray *rays, uint32_t n, pt_hit *hits, uint32_t *cursors, uint32_t cursor_count,
-                                                                             uint2 *spill, uint32_t spill_stride, DevStats *stats) {
-    __shared__ __attribute__((aligned(16))) unsigned long long lds[kHotEntries + kCachedWaves * wave_lds_entries<kCachedDepth>()];
-    constexpr int P = WIDE ? 8 : 4;  // 16-byte pieces per record
-    const uint32_t hot_count = WIDE ? S.hot4_count : S.hot2_count;
-    const float4 *src = WIDE ? reinterpret_cast<const float4 *>(S.nodes4) : reinterpret_cast<const float4 *>(S.nodes);
-    LdsF4 hot = (LdsF4)lds;
-    for (uint32_t i = threadIdx.x; i < hot_count * P; i += blockDim.x) {
-        const float4 v = src[i];
-        hot[hot_slot<P>(i / P, i % P)] = v4f{v.x, v.y, v.z, v.w};
-    }
-    __syncthreads();
-    const uint32_t wave_in_group = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t wave = blockIdx.x * kCachedWaves + wave_in_group;
-    unsigned long long *mine = lds + kHotEntries + wave_in_group * wave_lds_entries<kCachedDepth>();
-    const LaneStackT<kCachedDepth, true> stk{(LdsF4)(mine + kCachedDepth * kWave), (LdsU64)(mine + lane), reinterpret_cast<unsigned long long *>(spill + size_t(wave) * kWave) + lane,
-                                             spill_stride, hot, hot_count, wave};
-    LaneEvents ev;
-    ClosestIO<false> io{S, rays, hits, nullptr};
-    trace_stream<MODE_CLOSEST, false, WIDE>(S, io, n, make_feed(cursors, cursor_count, n), stk, ev);
-    flush_events(stats, ev);
-}
-
 template <bool COUNT>
 struct AnyIO {
     static constexpr bool kExactDistance = true;

@@ -17,7 +17,6 @@
 #include "debug_view.h"
 #include "bvh_build.h"
 #include "wide_bvh.h"
-#include "hot_nodes.h"
 #ifndef PT_WAVES_PER_CU
 #define PT_WAVES_PER_CU 16  // persistent waves per CU (4 per SIMD) of a ray query
 #endif
@@ -722,17 +721,7 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
         SetNodeChild(dn, 0, d->tlas_nodes[l].min, d->tlas_nodes[l].max, tlas_ref(l));
         SetNodeChild(dn, 1, d->tlas_nodes[r].min, d->tlas_nodes[r].max, tlas_ref(r));
     }
-    uint32_t root_ref = tlas_ref(0);
-
-    // squared linear scale of every instance of a tree, summed: how much world-space surface its boxes cover (hot_nodes.h)
-    std::vector<float> blas_scale(d->blas_count, 0.0f);
-    for (uint32_t i = 0; i < d->geometry_count; ++i) {
-        const float *T = d->geometries[i].transform;  // column-major 4x4
-        const double det = double(T[0]) * (double(T[5]) * T[10] - double(T[6]) * T[9]) - double(T[4]) * (double(T[1]) * T[10] - double(T[2]) * T[9]) +
-                           double(T[8]) * (double(T[1]) * T[6] - double(T[2]) * T[5]);
-        blas_scale[d->geometries[i].blas_index] += float(std::pow(std::fabs(det), 2.0 / 3.0));
-    }
-    std::vector<float> node_scale(nodes.size(), 1.0f);  // the top level is in world space already
+    const uint32_t root_ref = tlas_ref(0);
 
     std::vector<uint32_t> blas_root(d->blas_count, kNoRef);
     std::vector<uint32_t> node_map(d->blas_node_count, kNoRef);
@@ -744,7 +733,6 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
             if (d->blas_nodes[k].primitive_count == 0) {
                 node_map[k] = uint32_t(nodes.size());
                 nodes.emplace_back();
-                node_scale.push_back(blas_scale[b]);
             }
         for (uint32_t k = blas.first_node; k < blas.first_node + blas.node_count; ++k) {
             const pt_bvh_node &n = d->blas_nodes[k];
@@ -794,28 +782,10 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
         ptw::Box box(uint32_t i) const { return t->nodes[i].box; }
         uint32_t leaf_ref(uint32_t i) const { return kLeafBit | ids[t->nodes[i].item]; }
     };
-    uint32_t root_ref4 = top.nodes.empty() ? root_ref : ptw::Collapse(TopTree{&top, inst_ids.data()}, 0u, nodes4);
-    std::vector<float> node4_scale(nodes4.size(), 1.0f);
+    const uint32_t root_ref4 = top.nodes.empty() ? root_ref : ptw::Collapse(TopTree{&top, inst_ids.data()}, 0u, nodes4);
     std::vector<uint32_t> blas_root4(d->blas_count, kNoRef);
     for (uint32_t b = 0; b < d->blas_count; ++b)
-        if (d->blases[b].node_count > 0) {
-            blas_root4[b] = ptw::Collapse(BlasTree{d->blas_nodes, leaf_ref.data()}, d->blases[b].first_node, nodes4);
-            node4_scale.resize(nodes4.size(), blas_scale[b]);
-        }
-
-    // ---- the most visited records of both layouts go to the front of their arrays (hot_nodes.h)
-    uint32_t hot2 = 0, hot4 = 0;
-    if (!getenv("PTAMD_NO_HOT_NODES")) {
-        const std::vector<uint32_t> map2 = pth_hot::PutHotFirst(nodes, node_scale, pth_hot::kHot2);
-        root_ref = pth_hot::Renamed(root_ref, map2);
-        for (uint32_t &r : blas_root) r = pth_hot::Renamed(r, map2);
-        hot2 = uint32_t(std::min<size_t>(nodes.size(), pth_hot::kHot2));
-        const bool root4_is_binary = top.nodes.empty();  // no instance boxes: root_ref4 repeats root_ref (a leaf or nothing)
-        const std::vector<uint32_t> map4 = pth_hot::PutHotFirst(nodes4, node4_scale, pth_hot::kHot4);
-        root_ref4 = root4_is_binary ? root_ref : pth_hot::Renamed(root_ref4, map4);
-        for (uint32_t &r : blas_root4) r = pth_hot::Renamed(r, map4);
-        hot4 = uint32_t(std::min<size_t>(nodes4.size(), pth_hot::kHot4));
-    }
+        if (d->blases[b].node_count > 0) blas_root4[b] = ptw::Collapse(BlasTree{d->blas_nodes, leaf_ref.data()}, d->blases[b].first_node, nodes4);
     std::vector<uint32_t> inst_root4(d->geometry_count);
     for (uint32_t i = 0; i < d->geometry_count; ++i) inst_root4[i] = blas_root4[d->geometries[i].blas_index];
 
@@ -1041,8 +1011,6 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
     S.geometry_count = d->geometry_count;
     S.root_ref = root_ref;
     S.root_ref4 = root_ref4;
-    S.hot2_count = hot2;
-    S.hot4_count = hot4;
     for (int a = 0; a < 3; ++a) {
         S.root_min[a] = d->tlas_nodes[0].min[a];
         S.root_max[a] = d->tlas_nodes[0].max[a];
@@ -1529,24 +1497,7 @@ int pt_trace_closest(pt_ctx *ctx, const pt_ray *rays, size_t n, pt_hit *hits) {
     HIP_TRY(ctx, Join(ctx));  // lane 0's spill area is shared with render passes
     HIP_TRY(ctx, hipMemsetAsync(ctx->cursor, 0, size_t(ctx->query_cursors) * kCursorStride * sizeof(uint32_t), ctx->stream));
     const uint32_t blocks = uint32_t(std::min<size_t>(ctx->grid_blocks, (n + kWave - 1) / kWave));
-    // The usual grid, 16 waves per compute unit, runs as one workgroup per unit that keeps the hot node records in
-    // LDS (k_trace_closest_cached); other grid sizes (PTAMD_WAVES_PER_CU) and PTAMD_NODE_CACHE=0 use single-wave blocks.
-    static const bool node_cache = !(getenv("PTAMD_NODE_CACHE") && atoi(getenv("PTAMD_NODE_CACHE")) == 0);
-    if (node_cache && ctx->grid_blocks % kCachedWaves == 0) {
-        const uint32_t groups = uint32_t(std::min<size_t>(ctx->grid_blocks / kCachedWaves, (n + kCachedWaves * kWave - 1) / (kCachedWaves * kWave)));
-        DScene scene = ctx->scene;
-        if (const char *e = getenv("PTAMD_HOT_LIMIT")) {  // tuning aid: cache fewer records
-            scene.hot2_count = std::min<uint32_t>(scene.hot2_count, uint32_t(atoi(e)));
-            scene.hot4_count = std::min<uint32_t>(scene.hot4_count, uint32_t(atoi(e)));
-        }
-        ScopedEvent ev(ctx, EV_CLOSEST);
-        if (ctx->trace_mode & 2)
-            hipLaunchKernelGGL((k_trace_closest_cached<true>), dim3(groups), dim3(kCachedWaves * kWave), 0, ctx->stream, scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors,
-                               ctx->lane[0].spill, ctx->spill_stride, ctx->dev_stats);
-        else
-            hipLaunchKernelGGL((k_trace_closest_cached<false>), dim3(groups), dim3(kCachedWaves * kWave), 0, ctx->stream, scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors,
-                               ctx->lane[0].spill, ctx->spill_stride, ctx->dev_stats);
-    } else {
+    {
         ScopedEvent ev(ctx, EV_CLOSEST);
         if (ctx->trace_mode & 2)
             hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(blocks), dim3(kWave), 0, ctx->stream, ctx->scene, rays, uint32_t(n), hits, ctx->cursor, ctx->query_cursors,

@@ -584,8 +584,8 @@ PTD WorkFeed make_feed(uint32_t *cursors, uint32_t groups, uint32_t n) {
 // One work fetch: true and [base, end) when the wave got rays.  `dry` counts the cursors the wave
 // has found empty (wave-uniform; the feed is exhausted once dry == groups).  A fetch probes one
 // cursor, so a wave whose other lanes are still traversing waits for one round trip at most.
-PTD bool fetch_rays(const WorkFeed &feed, uint32_t wave, uint32_t n, uint32_t &dry, uint32_t &base, uint32_t &end) {
-    const uint32_t g = (wave + dry) % feed.groups;
+PTD bool fetch_rays(const WorkFeed &feed, uint32_t n, uint32_t &dry, uint32_t &base, uint32_t &end) {
+    const uint32_t g = (blockIdx.x + dry) % feed.groups;
     uint32_t t = 0;
     if ((threadIdx.x & 63u) == 0) t = atomicAdd(feed.cursors + size_t(g) * kCursorStride, 1u);
     t = __shfl(t, 0, 64);
@@ -617,22 +617,10 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
     const char *node_base = WIDE ? reinterpret_cast<const char *>(S.nodes4) : reinterpret_cast<const char *>(S.nodes);
     constexpr int kNodeShift = WIDE ? 7 : 6;  // 128-byte wide nodes, 64-byte binary ones
     constexpr int kNodeRegs = WIDE ? 7 : 4;   // 16-byte words of a node that the box tests read
-    // A node record comes out of the workgroup's LDS copy when its reference is below the cached count,
-    // through the vector memory pipeline otherwise.
 #ifdef PT_EXP_DOUBLE_LOAD
     float dup_word[kNodeRegs];
 #endif
     auto fetch_node = [&](uint32_t ref, float4(&nq)[kNodeRegs]) {
-        if constexpr (STK::kHot) {
-            if (ref < stk.hot_count) {
-#pragma unroll
-                for (int r = 0; r < kNodeRegs; ++r) {
-                    const v4f t = stk.hot[hot_slot<WIDE ? 8 : 4>(ref, uint32_t(r))];
-                    nq[r] = make_float4(t.x, t.y, t.z, t.w);
-                }
-                return;
-            }
-        }
         const float4 *np = reinterpret_cast<const float4 *>(node_base + (size_t(ref) << kNodeShift));
 #pragma unroll
         for (int r = 0; r < kNodeRegs; ++r) nq[r] = np[r];
@@ -656,7 +644,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
             for (;;) {
                 if (stage_next == stage_end) {  // restock
                     if (pool_next >= pool_end && !exhausted) {
-                        if (!fetch_rays(feed, stk.wave, n, dry, pool_next, pool_end)) exhausted = dry >= feed.groups;
+                        if (!fetch_rays(feed, n, dry, pool_next, pool_end)) exhausted = dry >= feed.groups;
                     }
                     if (pool_next >= pool_end) break;
                     const uint32_t count = (pool_end - pool_next < uint32_t(kWave)) ? pool_end - pool_next : uint32_t(kWave);
@@ -702,7 +690,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
         if (idle >= kRefillMin || idle == kWave) {
             io.flush();
             if (pool_next >= pool_end && !exhausted) {
-                if (!fetch_rays(feed, stk.wave, n, dry, pool_next, pool_end)) exhausted = dry >= feed.groups;
+                if (!fetch_rays(feed, n, dry, pool_next, pool_end)) exhausted = dry >= feed.groups;
             }
             if (pool_next < pool_end) {
                 const uint32_t prefix = __builtin_amdgcn_mbcnt_hi(uint32_t(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle_mask), 0u));

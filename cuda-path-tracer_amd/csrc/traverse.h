@@ -64,36 +64,21 @@ template <int DEPTH>
 constexpr int wave_lds_entries() { return DEPTH * kWave + kRayStageEntries; }
 constexpr int kWaveLdsEntries = wave_lds_entries<kLdsDepth>();
 
-template <int DEPTH, bool HOT = false>
+template <int DEPTH>
 struct LaneStackT {
     static constexpr int kDepth = DEPTH;  // entries per lane in LDS
-    static constexpr bool kHot = HOT;     // the workgroup keeps the most visited node records in LDS (hot_slot)
     LdsF4 stage;                // the wave's staged rays: (o.xyz, tmax) at [k], (d.xyz, valid) at [64 + k]
     LdsU64 lds;                 // this lane's column of the wave's LDS stack; entry k at lds[k * 64]
     unsigned long long *spill;  // this lane's column of the global spill area; entry k at spill[k * stride]
     uint32_t stride;            // lanes in the spill area
-    LdsF4 hot;                  // HOT: the cached node records, 16-byte pieces at hot[hot_slot<...>(node, piece)]
-    uint32_t hot_count;         // HOT: node references below this are cached
-    uint32_t wave;              // index of this wave in the grid (work feed, spill area)
 };
-
-// Where the cached copy of 16-byte piece `piece` of node record `node` lives.  A record of P pieces occupies P
-// consecutive slots, rotated by a function of the node index so that lanes reading the same piece of
-// different records spread over all LDS banks (16 consecutive records map to 16 different bank groups);
-// lanes that read the same record share one access.
-template <int P>
-PTD uint32_t hot_slot(uint32_t node, uint32_t piece) {
-    static_assert(P == 4 || P == 8, "64-byte binary records or 128-byte 4-wide records");
-    const uint32_t rot = P == 8 ? (node >> 1) : (node >> 2);
-    return node * P + ((piece + rot) & (P - 1));
-}
 
 // `lds_array` is the kernel's __shared__ array of wave_lds_entries<DEPTH>() entries, `spill_base` the wave's
 // first column of the global spill area.
 template <int DEPTH = kLdsDepth>
 PTD LaneStackT<DEPTH> make_lane_stack(unsigned long long *lds_array, uint2 *spill_base, uint32_t stride) {
     const uint32_t lane = threadIdx.x & 63u;
-    return LaneStackT<DEPTH>{(LdsF4)(lds_array + DEPTH * kWave), (LdsU64)(lds_array + lane), reinterpret_cast<unsigned long long *>(spill_base) + lane, stride, (LdsF4) nullptr, 0u, blockIdx.x};
+    return LaneStackT<DEPTH>{(LdsF4)(lds_array + DEPTH * kWave), (LdsU64)(lds_array + lane), reinterpret_cast<unsigned long long *>(spill_base) + lane, stride};
 }
 
 struct HitRec {
