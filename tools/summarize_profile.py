@@ -64,10 +64,14 @@ def sq_binding(base, kernel=EXACT):
     if vals.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
         out["tcp_accesses_per_cycle_per_cu"] = vals["TCP_TOTAL_CACHE_ACCESSES_sum"] / (256.0 * kernel_cycles)
         out["l1_hit_frac"] = 1.0 - vals.get("TCP_TCC_READ_REQ_sum", 0.0) / vals["TCP_TOTAL_CACHE_ACCESSES_sum"]
-    out["resource"] = ("VALU issue: valu_busy_frac is every vector instruction priced at 4 cycles of its SIMD over the launch (measured per "
-                       "instruction class, profiles/r2_ubench_*.txt: 2.7 cycles for fp32 add / mul / fma, 4 to 4.7 for min / max / compare / select / "
-                       "integer, so the true share lies a little below), at lane_utilisation of the lanes, 4 waves per SIMD (registers and 10 KB of "
-                       "LDS per wave both allow no more); HBM carries a few per cent of the algorithmic bytes")
+    out["resource"] = ("waves in flight: 16 per CU is all that 116-128 registers and 10 KB of LDS per wave allow (about 620 B of on-chip state per "
+                       "ray, 95 % of a CU's register file + LDS), and with 4 waves per SIMD neither pipe is full: the vector ALUs are busy "
+                       "valu_busy_frac of the launch with every instruction priced at 4 cycles (measured per class, profiles/r2_ubench_*.txt: 2.7 "
+                       "for fp32 add / mul / fma, 4 to 4.7 for min / max / compare / select / integer) at lane_utilisation of the lanes, the L1 "
+                       "takes tcp_accesses_per_cycle_per_cu lane requests against 1.7 measured for dependent gathers.  The launch time follows the "
+                       "wave count (8 / 12 / 16 waves per CU: 2.54 / 1.99 / 1.68 ms) and the length of a round: every slab test evaluated twice "
+                       "costs 9-13 %, every node piece requested twice 30-46 %, a third of the node visits served from LDS nothing, because a round "
+                       "waits for its slowest lane (profiles/r2_load_vs_valu_sensitivity.txt).  HBM carries a few per cent of the algorithmic bytes")
     out["source"] = "tools/profile_sq.sh: rocprofv3 --pmc, three separate passes over bench.py --steps 3 --spp-steps 0"
     return out
 
