@@ -1380,7 +1380,8 @@ const RcclApi *Rccl() {
         if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;  // a copy the process already holds
     for (size_t k = 0; !lib && k < sizeof(kNames) / sizeof(kNames[0]); ++k) lib = dlopen(kNames[k], RTLD_NOW | RTLD_LOCAL);
     if (!lib) {
-        g_rccl.error = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "not found");
+        const char *why = dlerror();  // one call: dlerror() clears the message it returns
+        g_rccl.error = std::string("librccl could not be loaded: ") + (why ? why : "not found");
         return nullptr;
     }
     RcclApi api;
