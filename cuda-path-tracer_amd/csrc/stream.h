@@ -620,17 +620,6 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
 #ifdef PT_EXP_DOUBLE_LOAD
     float dup_word[kNodeRegs];
 #endif
-    auto fetch_node = [&](uint32_t ref, float4(&nq)[kNodeRegs]) {
-        const float4 *np = reinterpret_cast<const float4 *>(node_base + (size_t(ref) << kNodeShift));
-#pragma unroll
-        for (int r = 0; r < kNodeRegs; ++r) nq[r] = np[r];
-#ifdef PT_EXP_DOUBLE_LOAD
-        // one more request per 16-byte piece, issued with the others and consumed only after the node has been
-        // used, so that the round's chain of dependent waits stays what it was
-#pragma unroll
-        for (int r = 0; r < kNodeRegs; ++r) asm volatile("global_load_dword %0, %1, off offset:4" : "=v"(dup_word[r]) : "v"(np + r));  // a plain cached load the compiler cannot merge
-#endif
-    };
 #if PT_STAGE_RAYS
     // Rays are read 64 at a time, by all lanes together, into the wave's LDS, and handed to lanes as
     // they fall idle: the wave then waits for a gather from path state (thousands of cycles when the
@@ -732,7 +721,17 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
             const bool w_int = active && tr.wants_interior();
             const bool go = __builtin_popcountll(int_mask) >= vote_int;
             float4 nq[kNodeRegs];
-            if (go && w_int) fetch_node(tr.cur, nq);
+            if (go && w_int) {
+                const float4 *np = reinterpret_cast<const float4 *>(node_base + (size_t(tr.cur) << kNodeShift));
+#pragma unroll
+                for (int r = 0; r < kNodeRegs; ++r) nq[r] = np[r];
+#ifdef PT_EXP_DOUBLE_LOAD
+                // one more request per 16-byte piece, issued with the others and consumed only after the node has been
+                // used, so that the round's chain of dependent waits stays what it was
+#pragma unroll
+                for (int r = 0; r < kNodeRegs; ++r) asm volatile("global_load_dword %0, %1, off offset:4" : "=v"(dup_word[r]) : "v"(np + r));  // a plain cached load the compiler cannot merge
+#endif
+            }
 #if !PT_POP_FIRST
             if (active && tr.wants_pop()) {
                 PT_PHASE(ev, 3);
@@ -782,8 +781,10 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
 #ifdef PT_NODE_HIST
                 atomicAdd(&g_node_hist[tr.cur < kNodeHistSize ? tr.cur : kNodeHistSize - 1], 1u);
 #endif
+                const float4 *np = reinterpret_cast<const float4 *>(node_base + (size_t(tr.cur) << kNodeShift));
                 float4 nq[kNodeRegs];
-                fetch_node(tr.cur, nq);
+#pragma unroll
+                for (int r = 0; r < kNodeRegs; ++r) nq[r] = np[r];
                 if constexpr (WIDE) tr.op_interior4(stk, ev, nq);
                 else tr.op_interior(stk, ev, nq[0], nq[1], nq[2], nq[3]);
             }
