@@ -172,6 +172,23 @@ private:
     }
 };
 
+// A JSON number used as a count, an index or an integer option.  Converting a double that is not finite, or
+// that lies outside the target type's range, to an integer is undefined behaviour: such values end in an error.
+long long Whole(double v, const char *what) {
+    if (!(v >= -9.0e15 && v <= 9.0e15)) throw Exception(std::string("'") + what + "' is not a usable whole number");  // NaN fails both comparisons
+    return static_cast<long long>(v);
+}
+int WholeInt(double v, const char *what) {
+    const long long w = Whole(v, what);
+    if (w < -2147483647LL - 1 || w > 2147483647LL) throw Exception(std::string("'") + what + "' is outside the range of a 32-bit integer");
+    return static_cast<int>(w);
+}
+size_t WholeSize(double v, const char *what) {
+    const long long w = Whole(v, what);
+    if (w < 0) throw Exception(std::string("'") + what + "' is negative");
+    return static_cast<size_t>(w);
+}
+
 std::string ReadFile(const std::string &path, bool binary = true) {
     std::ifstream f(path, binary ? std::ios::binary : std::ios::in);
     if (!f) throw Exception("could not open file '" + path + "'");
@@ -371,23 +388,23 @@ public:
         int file_w = 800, file_h = 800;
         if (m_legacy) {
             cam = data.find("Camera");
-            depth = int(NumberOr(*cam, "DEPTH", 4));
-            iterations = int(NumberOr(*cam, "ITERATIONS", 1000));
+            depth = WholeInt(NumberOr(*cam, "DEPTH", 4), "DEPTH");
+            iterations = WholeInt(NumberOr(*cam, "ITERATIONS", 1000), "ITERATIONS");
             if (const Json *res = cam->find("RES"); res && res->is_array() && res->arr.size() == 2) {
-                file_w = int(res->arr[0].num);
-                file_h = int(res->arr[1].num);
+                file_w = WholeInt(res->arr[0].num, "RES");
+                file_h = WholeInt(res->arr[1].num, "RES");
             }
         } else {
             if (const Json *in = data.find("integrator")) {  // ParseIntegrator, scene.cpp:156-173
-                depth = int(NumberOr(*in, "DEPTH", 4));
-                iterations = int(NumberOr(*in, "ITERATIONS", 1000));
+                depth = WholeInt(NumberOr(*in, "DEPTH", 4), "DEPTH");
+                iterations = WholeInt(NumberOr(*in, "ITERATIONS", 1000), "ITERATIONS");
             }
             cam = data.find("camera");
             if (!cam) throw Exception("scene '" + path + "' has no camera");
             const Json *film = cam->find("film");
             if (!film || !film->has("WIDTH") || !film->has("HEIGHT")) throw Exception("scene '" + path + "': camera.film needs WIDTH and HEIGHT");
-            file_w = int(film->find("WIDTH")->num);
-            file_h = int(film->find("HEIGHT")->num);
+            file_w = WholeInt(film->find("WIDTH")->num, "WIDTH");
+            file_h = WholeInt(film->find("HEIGHT")->num, "HEIGHT");
         }
         S.SetIntegrator(max_depth > 0 ? max_depth : depth, iterations);
         Camera &c = S.GetCamera();  // ParseCamera, scene.cpp:175-233
@@ -676,17 +693,17 @@ private:
         const std::vector<Json> &accessors = Need(g.j, "accessors", Json::Array).arr, &views = Need(g.j, "bufferViews", Json::Array).arr;
         if (index < 0 || size_t(index) >= accessors.size()) throw Exception("glTF: accessor index out of range");
         const Json &acc = accessors[size_t(index)];
-        const size_t view_index = size_t(NumberOr(acc, "bufferView", 0));
+        const size_t view_index = WholeSize(NumberOr(acc, "bufferView", 0), "bufferView");
         if (view_index >= views.size()) throw Exception("glTF: bufferView index out of range");
         const Json &view = views[view_index];
-        const int ctype = int(NumberOr(acc, "componentType", 5126));
+        const int ctype = WholeInt(NumberOr(acc, "componentType", 5126), "componentType");
         const size_t size = ComponentSize(ctype);
         ncomp = ComponentCount(StringOr(acc, "type", "SCALAR"));
-        count = size_t(NumberOr(acc, "count", 0));
-        size_t stride = size_t(NumberOr(view, "byteStride", 0));
+        count = WholeSize(NumberOr(acc, "count", 0), "count");
+        size_t stride = WholeSize(NumberOr(view, "byteStride", 0), "byteStride");
         if (stride == 0) stride = size * size_t(ncomp);
-        const size_t start = size_t(NumberOr(view, "byteOffset", 0)) + size_t(NumberOr(acc, "byteOffset", 0));
-        const size_t buffer_index = size_t(NumberOr(view, "buffer", 0));
+        const size_t start = WholeSize(NumberOr(view, "byteOffset", 0), "byteOffset") + WholeSize(NumberOr(acc, "byteOffset", 0), "byteOffset");
+        const size_t buffer_index = WholeSize(NumberOr(view, "buffer", 0), "buffer");
         if (buffer_index >= g.buffers.size()) throw Exception("glTF: buffer index out of range");
         const std::string &buf = g.buffers[buffer_index];
         if (count > buf.size()) throw Exception("glTF: accessor count exceeds its buffer");  // every element takes at least a byte
@@ -717,11 +734,11 @@ private:
             return ReadFile(Join(g.dir, uri->str));
         }
         const std::vector<Json> &views = Need(g.j, "bufferViews", Json::Array).arr;
-        const size_t view_index = size_t(NumberOr(im, "bufferView", 0));
+        const size_t view_index = WholeSize(NumberOr(im, "bufferView", 0), "bufferView");
         if (view_index >= views.size()) throw Exception("glTF: bufferView index out of range");
         const Json &view = views[view_index];
-        const size_t off = size_t(NumberOr(view, "byteOffset", 0)), len = size_t(NumberOr(view, "byteLength", 0));
-        const size_t buffer_index = size_t(NumberOr(view, "buffer", 0));
+        const size_t off = WholeSize(NumberOr(view, "byteOffset", 0), "byteOffset"), len = WholeSize(NumberOr(view, "byteLength", 0), "byteLength");
+        const size_t buffer_index = WholeSize(NumberOr(view, "buffer", 0), "buffer");
         if (buffer_index >= g.buffers.size() || off > g.buffers[buffer_index].size()) throw Exception("glTF: image bufferView out of range");
         return g.buffers[buffer_index].substr(off, len);
     }
@@ -744,26 +761,26 @@ private:
             for (const Json &mesh : meshes->arr) {
                 std::vector<Prim> prims;
                 for (const Json &prim : Need(mesh, "primitives", Json::Array).arr) {
-                    if (int(NumberOr(prim, "mode", 4)) != 4) continue;
+                    if (WholeInt(NumberOr(prim, "mode", 4), "mode") != 4) continue;
                     const Json &attrs = Need(prim, "attributes", Json::Object);
                     std::vector<double> pos, nrm, uv, idx;
                     int nc;
                     size_t vc, cnt;
-                    ReadAccessor(g, int(Need(attrs, "POSITION", Json::Number).num), pos, nc, vc);
+                    ReadAccessor(g, WholeInt(Need(attrs, "POSITION", Json::Number).num, "POSITION"), pos, nc, vc);
                     if (nc != 3) throw Exception("glTF: POSITION must be VEC3");
                     const bool use_face = face_normals || !attrs.has("NORMAL");
                     if (!use_face) {
-                        ReadAccessor(g, int(Need(attrs, "NORMAL", Json::Number).num), nrm, nc, cnt);
+                        ReadAccessor(g, WholeInt(Need(attrs, "NORMAL", Json::Number).num, "NORMAL"), nrm, nc, cnt);
                         if (nc != 3 || cnt != vc) throw Exception("glTF: NORMAL must be VEC3 with one entry per vertex");
                     }
                     const bool has_uv = attrs.has("TEXCOORD_0");
                     if (has_uv) {
-                        ReadAccessor(g, int(Need(attrs, "TEXCOORD_0", Json::Number).num), uv, nc, cnt);
+                        ReadAccessor(g, WholeInt(Need(attrs, "TEXCOORD_0", Json::Number).num, "TEXCOORD_0"), uv, nc, cnt);
                         if (nc != 2 || cnt != vc) throw Exception("glTF: TEXCOORD_0 must be VEC2 with one entry per vertex");
                     }
                     std::vector<uint32_t> indices;
                     if (prim.has("indices")) {
-                        ReadAccessor(g, int(Need(prim, "indices", Json::Number).num), idx, nc, cnt);
+                        ReadAccessor(g, WholeInt(Need(prim, "indices", Json::Number).num, "indices"), idx, nc, cnt);
                         indices.resize(idx.size());
                         for (size_t k = 0; k < idx.size(); ++k) {
                             if (!(idx[k] >= 0.0 && idx[k] < double(vc))) throw Exception("glTF: vertex index out of range");
@@ -801,7 +818,7 @@ private:
                         }
                         out_vc = uint32_t(indices.size());
                     }
-                    const int material = std::max(int(NumberOr(prim, "material", 0)), 0);
+                    const int material = std::max(WholeInt(NumberOr(prim, "material", 0), "material"), 0);
                     prims.push_back(Prim{first_index, uint32_t(indices.size()), out_vc, material});
                 }
                 mesh_prims.push_back(std::move(prims));
@@ -822,9 +839,9 @@ private:
                 const Json *pbr = mat.find("pbrMetallicRoughness");
                 auto source_of = [&](const Json &ref) {
                     const std::vector<Json> &textures = Need(g.j, "textures", Json::Array).arr;
-                    const size_t index = size_t(NumberOr(ref, "index", 0));
+                    const size_t index = WholeSize(NumberOr(ref, "index", 0), "index");
                     if (index >= textures.size()) throw Exception("glTF: texture index out of range");
-                    return int(NumberOr(textures[index], "source", 0));
+                    return WholeInt(NumberOr(textures[index], "source", 0), "source");
                 };
                 if (pbr && pbr->has("baseColorTexture")) {
                     const int src = source_of(*pbr->find("baseColorTexture"));
@@ -876,21 +893,21 @@ private:
             const Mat4 local = Mul(Mul(Mul(Translate(I, t), FromQuat(q[0], q[1], q[2], q[3])), Scale(I, s)), matrix);
             Node node;
             node.world = Mul(parent, local);
-            node.mesh = int(NumberOr(n, "mesh", -1));
+            node.mesh = WholeInt(NumberOr(n, "mesh", -1), "mesh");
             const int self = int(nodes.size());
             nodes.push_back(node);
             if (const Json *ch = n.find("children"))
                 for (const Json &c : ch->arr) {
-                    const int child = load_node(int(c.num), nodes[size_t(self)].world);
+                    const int child = load_node(WholeInt(c.num, "node index"), nodes[size_t(self)].world);
                     nodes[size_t(self)].children.push_back(child);
                 }
             return self;
         };
         std::vector<int> stack;
-        const int scene_index = int(NumberOr(g.j, "scene", 0));
+        const int scene_index = WholeInt(NumberOr(g.j, "scene", 0), "scene");
         const std::vector<Json> &scenes = Need(g.j, "scenes", Json::Array).arr;
         if (scene_index < 0 || size_t(scene_index) >= scenes.size()) throw Exception("glTF: scene index out of range");
-        for (const Json &r : Need(scenes[size_t(scene_index)], "nodes", Json::Array).arr) stack.push_back(load_node(int(r.num), Mat4::Identity()));
+        for (const Json &r : Need(scenes[size_t(scene_index)], "nodes", Json::Array).arr) stack.push_back(load_node(WholeInt(r.num, "node index"), Mat4::Identity()));
         std::vector<int> order;
         while (!stack.empty()) {
             const int cur = stack.back();

@@ -23,7 +23,7 @@ class PtError(RuntimeError):
 
 def _host_check(status: int):
     if status != abi.PT_OK:
-        raise PtError(status, abi.load_library().pth_last_error().decode())
+        raise PtError(status, abi.load_library().pth_last_error().decode(errors="replace"))
 
 
 def _f3(v):

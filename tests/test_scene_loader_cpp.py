@@ -212,6 +212,10 @@ def test_malformed_files_end_in_an_error_not_a_crash(pt, tmp_path):
     damaged(lambda g: g["scenes"][0].update(nodes=[5]), "node index")
     damaged(lambda g: g["nodes"][0].update(children=[0]), "not a tree")
     damaged(lambda g: g["nodes"][0].update(matrix=[1, 0, 0]), "too few numbers")
+    # numbers that no integer can hold (their conversion would be undefined behaviour) are refused by name
+    damaged(lambda g: g["accessors"][2].update(count=1e40), "'count' is not a usable whole number")
+    damaged(lambda g: g["meshes"][0]["primitives"][0].update(material=2147483648), "'material' is outside the range")
+    damaged(lambda g: g["accessors"][0].update(byteOffset=-4), "'byteOffset' is negative")
     (tmp_path / "t.gltf").write_text(json.dumps(good))
     pt.HostScene.load(scene_path)
 
