@@ -54,6 +54,12 @@ bool ReadCheckpoint(const std::string &path, int &width, int &height, uint32_t &
     CheckpointHeader h{};
     bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, kMagic, sizeof(kMagic)) == 0 && h.width > 0 && h.height > 0 &&
               h.width <= 65536 && h.height <= 65536;
+    if (ok) {  // the file holds exactly the film its header announces: nothing is allocated on a header's word alone
+        const long at = std::ftell(f);
+        ok = at >= 0 && std::fseek(f, 0, SEEK_END) == 0;
+        const long size = ok ? std::ftell(f) : -1;
+        ok = ok && size >= at && uint64_t(size - at) == uint64_t(h.width) * uint64_t(h.height) * 3u * sizeof(float) && std::fseek(f, at, SEEK_SET) == 0;
+    }
     if (ok && film) {
         film->resize(size_t(h.width) * h.height * 3);
         ok = std::fread(film->data(), sizeof(float), film->size(), f) == film->size();

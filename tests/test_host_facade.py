@@ -271,3 +271,7 @@ def test_checkpoint_reader_rejects_foreign_files(pt, tmp_path):
     p.write_bytes(b"PTFILM1\0" + struct.pack("<iiII", 2, 1, 7, 0) + np.arange(5, dtype=np.float32).tobytes())  # truncated
     with pytest.raises(pt.PtError, match="not a film checkpoint"):
         pt.checkpoint_read(str(p))
+    # a header that announces a 51 GB film over a 24-byte body is refused before anything is allocated
+    p.write_bytes(b"PTFILM1\0" + struct.pack("<iiII", 65536, 65536, 7, 0) + np.arange(6, dtype=np.float32).tobytes())
+    with pytest.raises(pt.PtError, match="not a film checkpoint"):
+        pt.checkpoint_read(str(p))
