@@ -554,7 +554,7 @@ constexpr uint32_t kNoRayBits = 0x7FC0DEADu;  // t_max bit pattern (a NaN no com
 #define PT_VOTE_RARE 8   // lanes that make an instance enter / level change round worth running
 #endif
 #ifndef PT_VOTE_LEVEL
-#define PT_VOTE_LEVEL PT_VOTE_RARE
+#define PT_VOTE_LEVEL 12  // lanes that make a level change round worth running (8 / 12 / 16: 1.56 / 1.53 / 1.54 ms on the bench batch)
 #endif
 constexpr int kRefillMin = PT_REFILL_MIN;
 
