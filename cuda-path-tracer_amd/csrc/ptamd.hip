@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -763,13 +764,36 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
         ptw::Box box(uint32_t i) const { return ptw::Box{{n[i].min[0], n[i].min[1], n[i].min[2]}, {n[i].max[0], n[i].max[1], n[i].max[2]}}; }
         uint32_t leaf_ref(uint32_t i) const { return leaf_refs[i]; }
     };
-    // the top level is rebuilt over the reference's TLAS leaves (instance world boxes, bvh.cpp:273-280)
+    // The top level is rebuilt over the reference's TLAS leaves (instance world boxes, bvh.cpp:273-280), each
+    // clipped to the world box of the transformed mesh itself (wide_bvh.h, TightInstanceBox).
+    struct MeshTree : BlasTree {
+        const pt_bvh_node *nodes;
+        const DTri *records;  // the BLAS's triangle records (object space), leaf order
+        uint32_t first_index;
+        void for_each_vertex(uint32_t i, const std::function<void(float, float, float)> &f) const {
+            for (uint32_t k = 0; k < nodes[i].primitive_count; ++k) {
+                const DTri &t = records[first_index + nodes[i].first_primitive + k];
+                f(t.a.x, t.a.y, t.a.z);
+                f(t.a.w, t.b.x, t.b.y);
+                f(t.b.z, t.b.w, t.c.x);
+            }
+        }
+    };
+    const bool tight_boxes = !getenv("PTAMD_LOOSE_INSTANCE_BOXES");
     std::vector<ptw::Box> inst_boxes;
     std::vector<uint32_t> inst_ids;
     for (uint32_t i = 0; i < d->tlas_node_count; ++i) {
         const pt_tlas_node &n = d->tlas_nodes[i];
         if (n.left_right != 0 || (i == 0 && d->tlas_node_count > 1)) continue;  // interior node, or the root's copy of a lone leaf
-        inst_boxes.push_back(ptw::Box{{n.min[0], n.min[1], n.min[2]}, {n.max[0], n.max[1], n.max[2]}});
+        const ptw::Box loose{{n.min[0], n.min[1], n.min[2]}, {n.max[0], n.max[1], n.max[2]}};
+        const pt_geometry_instance &g = d->geometries[n.instance];
+        const pt_blas &blas = d->blases[g.blas_index];
+        if (tight_boxes && blas.node_count > 0) {
+            MeshTree mesh{{d->blas_nodes, leaf_ref.data()}, d->blas_nodes, tris.data(), blas.first_index};
+            inst_boxes.push_back(ptw::TightInstanceBox(mesh, blas.first_node, g.transform, loose));
+        } else {
+            inst_boxes.push_back(loose);
+        }
         inst_ids.push_back(n.instance);
     }
     const ptw::TopLevel top = ptw::BuildTopLevel(inst_boxes.data(), uint32_t(inst_boxes.size()));

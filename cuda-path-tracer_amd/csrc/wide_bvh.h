@@ -225,4 +225,66 @@ inline TopLevel BuildTopLevel(const Box *boxes, uint32_t n) {
     return t;
 }
 
+
+// A tighter world-space box for an instance than the reference's (the world box of the transformed corners of
+// the mesh's object-space box, bvh.cpp:273-280, which for a rotated mesh has up to three times the surface,
+// so that most rays crossing it miss the mesh).  The extent of the transformed mesh along world axis a is the
+// mesh's support function in the direction of row a of the transform, and the mesh's own BVH finds that by
+// branch and bound: a box is opened only while its own support can still beat the best vertex found.
+//
+// Tree: is_leaf(i), left(i), right(i), box(i) as for Collapse, plus for_each_vertex(i, f) calling f(x, y, z)
+// for the corners of the triangles of leaf i.  Returns max over the mesh's vertices of dir . v; when the search is
+// cut short after `budget` boxes the unopened boxes' own supports are folded in, so the result never falls short.
+template <class Tree>
+double MeshSupport(const Tree &tree, uint32_t root, const double dir[3], int budget = 4096) {
+    auto box_support = [&](uint32_t n) {
+        const Box b = tree.box(n);
+        double s = 0.0;
+        for (int a = 0; a < 3; ++a) s += std::fmax(dir[a] * double(b.mn[a]), dir[a] * double(b.mx[a]));
+        return s;
+    };
+    double best = -INFINITY;
+    std::vector<uint32_t> stack{root};
+    while (!stack.empty()) {
+        const uint32_t n = stack.back();
+        stack.pop_back();
+        const double ub = box_support(n);
+        if (!(ub > best)) continue;
+        if (--budget < 0) {
+            best = std::fmax(best, ub);  // not opened: its own support stands in for its vertices
+            continue;
+        }
+        if (tree.is_leaf(n)) {
+            tree.for_each_vertex(n, [&](float x, float y, float z) { best = std::fmax(best, dir[0] * double(x) + dir[1] * double(y) + dir[2] * double(z)); });
+        } else {
+            const uint32_t l = tree.left(n), r = tree.right(n);
+            const bool left_first = box_support(l) >= box_support(r);
+            stack.push_back(left_first ? r : l);
+            stack.push_back(left_first ? l : r);  // the more promising child is opened first
+        }
+    }
+    return best;
+}
+
+// The world box of the transformed mesh (column-major 4x4 transform), widened by a rounding margin and clipped
+// to the reference's box: it contains every transformed triangle and never exceeds what the reference tests.
+// A ray that misses it cannot hit the instance, so skipping the instance changes no result.
+template <class Tree>
+Box TightInstanceBox(const Tree &tree, uint32_t root, const float *transform, const Box &reference_box) {
+    Box r;
+    for (int a = 0; a < 3; ++a) {
+        const double row[3] = {double(transform[a]), double(transform[4 + a]), double(transform[8 + a])};
+        const double neg[3] = {-row[0], -row[1], -row[2]};
+        const double hi = MeshSupport(tree, root, row) + double(transform[12 + a]);
+        const double lo = -MeshSupport(tree, root, neg) + double(transform[12 + a]);
+        // a few units in the last place of the largest coordinate involved: the reference moves the ray into
+        // object space instead, and the two roundings must not disagree about a triangle on the box's face
+        const double margin = 1e-5 * std::fmax(std::fmax(std::fabs(lo), std::fabs(hi)), hi - lo);
+        r.mn[a] = std::fmax(float(lo - margin), reference_box.mn[a]);
+        r.mx[a] = std::fmin(float(hi + margin), reference_box.mx[a]);
+        if (!(r.mn[a] <= r.mx[a])) return reference_box;  // not finite, or clipped away: keep the reference's box
+    }
+    return r;
+}
+
 }  // namespace ptw

@@ -493,7 +493,9 @@ int pt_capture_shadow_rays(pt_ctx *ctx, int width, int height, int iteration, in
  *   on 2.1 M captured shadow rays of three scenes and against mode 0 on 17.6 M of five: no flag differs.
  * Bit 1 (modes 2, 3): the trees are walked as 4-wide nodes (128 bytes: the reference's own fp32 boxes
  *   of four children, tested with the reference's arithmetic), the top level is rebuilt top down over
- *   the reference's instance boxes, and the search inside an instance is bounded by the best hit of
+ *   the reference's instance boxes, each clipped to the world box of its transformed mesh (the reference's
+ *   box of a rotated mesh is the box of a rotated box, bvh.cpp:273-280; a ray that misses the clipped box
+ *   cannot hit the instance), and the search inside an instance is bounded by the best hit of
  *   the instances visited before.  Every box decides as in the reference; the visiting order differs,
  *   so rays with two triangles at the same distance may report the other one (same t to rounding;
  *   all other rays get bit-identical records), and the 64-entry stack limit of the reference
