@@ -230,7 +230,8 @@ inline TopLevel BuildTopLevel(const Box *boxes, uint32_t n) {
 // the mesh's object-space box, bvh.cpp:273-280, which for a rotated mesh has up to three times the surface,
 // so that most rays crossing it miss the mesh).  The extent of the transformed mesh along world axis a is the
 // mesh's support function in the direction of row a of the transform, and the mesh's own BVH finds that by
-// branch and bound: a box is opened only while its own support can still beat the best vertex found.
+// branch and bound: a box is opened only while its own support can still beat the best vertex found (which
+// relies on every node's box containing the triangles under it, as any BVH builder's do).
 //
 // Tree: is_leaf(i), left(i), right(i), box(i) as for Collapse, plus for_each_vertex(i, f) calling f(x, y, z)
 // for the corners of the triangles of leaf i.  Returns max over the mesh's vertices of dir . v; when the search is
