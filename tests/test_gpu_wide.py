@@ -163,6 +163,95 @@ def test_wide_batched_render_is_reproducible_and_equals_mode_0_almost_everywhere
     assert differing <= 1e-3, differing
 
 
+def _rotated_ellipsoids_scene(pt, count=60, seed=5):
+    """Flat ellipsoids (a sphere mesh scaled to 3 x 0.15 x 0.6) at random rotations: the reference's instance box,
+    the box of the rotated object-space box, is much larger than the ellipsoid's own world box."""
+    rng = np.random.default_rng(seed)
+    hs = pt.HostScene()
+    hs.set_integrator(4, 4)
+    hs.set_camera([0.0, 0.0, 12.0], [0.0, 0.0, 0.0], [0.0, 1.0, 0.0], 50.0, 64, 48)
+    white = hs.add_constant_texture3([0.8, 0.8, 0.8])
+    mat = hs.add_material(pt.abi.PT_MAT_LAMBERTIAN, white)
+    cp, cn, ct, ci = pt.uv_sphere(10, 20)
+    first = hs.add_mesh(cp, cn, ct, ci)
+    blas = hs.new_blas_index()
+    transforms = []
+    for _ in range(count):
+        t = pt.transform_matrix(list(rng.uniform(-3, 3, 3)), list(rng.uniform(0, 360, 3)), [3.0, 0.15, 0.6])
+        transforms.append(np.asarray(t, np.float32).reshape(4, 4).T)  # column-major float[16] -> matrix
+        hs.add_instance(first, len(ci), len(cp), mat, t, blas)
+    hs.finalize()
+    return hs, cp, transforms
+
+
+def test_clipped_instance_boxes_change_no_result_and_skip_instances(pt, ora, wide_ctx, devbuf, monkeypatch):
+    """The 4-wide layout's top level holds each instance's box clipped to the world box of its transformed mesh
+    (wide_bvh.h).  On rotated flat ellipsoids - incoherent rays, and rays aimed at every vertex, among them the ones
+    that lie on the faces of the clipped boxes - the records equal the oracle's, and fewer instances are entered than
+    with the reference's boxes."""
+    hs, corners, transforms = _rotated_ellipsoids_scene(pt)
+    desc = hs.desc()
+    n_inc = 200000
+    rays_d = devbuf(n_inc * 32)
+    wide_ctx.upload(desc)
+    wide_ctx.generate_incoherent_rays(rays_d.ptr, n_inc, 77)
+    wide_ctx.synchronize()
+    inc = rays_d.download(pt.abi.RAY, n_inc)
+    # rays from outside towards the world position of every vertex of every ellipsoid, from three sides each
+    targets = []
+    for m in transforms:
+        for c in corners:
+            targets.append((m @ np.append(c, 1.0).astype(np.float32))[:3])
+    targets = np.asarray(targets, np.float32)
+    origins, dirs = [], []
+    for axis in range(3):
+        o = targets.copy()
+        o[:, axis] += 20.0
+        origins.append(o)
+        dirs.append(targets - o)
+    aimed = rays_from_arrays(pt, np.concatenate(origins), np.concatenate(dirs))
+    rays = np.concatenate([inc, aimed])
+    n = len(rays)
+    ref = ora.trace_closest(desc, rays, nthreads=8)
+    assert (ref["inst"] >= 0).sum() > n // 20
+
+    import torch
+
+    def run():
+        buf, hits_d, ctr_d = devbuf(n * 32), devbuf(n * 32), devbuf(n * 16)
+        buf.upload(torch, rays)
+        wide_ctx.trace_closest_counted(buf.ptr, n, hits_d.ptr, ctr_d.ptr)
+        wide_ctx.synchronize()
+        return hits_d.download(pt.abi.HIT, n), ctr_d.download(np.uint32, n * 4).reshape(n, 4)
+
+    def check(h):
+        # incoherent rays: the usual bar.  A ray through a vertex meets all the triangles around it at one
+        # distance, and which of them a layout reports is its visiting order: there the instance, the distance and
+        # hit-against-miss have to agree, not the triangle.
+        _check_closest(h[:n_inc], ref[:n_inc], n_inc)
+        a, r = h[n_inc:], ref[n_inc:]
+        assert np.array_equal(a["inst"] >= 0, r["inst"] >= 0)
+        both = r["inst"] >= 0
+        assert both.sum() > len(r) // 2
+        assert (a["inst"][both] != r["inst"][both]).sum() <= 2  # two ellipsoids can meet at a vertex
+        same = both & (a["inst"] == r["inst"])
+        assert np.max(np.abs(a["t"][same] - r["t"][same]) / np.abs(r["t"][same])) <= 1e-5
+
+    hits, ctr = run()
+    check(hits)
+    monkeypatch.setenv("PTAMD_LOOSE_INSTANCE_BOXES", "1")
+    wide_ctx.upload(desc)
+    hits_loose, ctr_loose = run()
+    monkeypatch.delenv("PTAMD_LOOSE_INSTANCE_BOXES")
+    wide_ctx.upload(desc)
+    check(hits_loose)
+    # the clipped boxes only skip instances that hold nothing for the ray: the records do not depend on them
+    differ = (hits["prim"] != hits_loose["prim"]) | (hits["inst"] != hits_loose["inst"]) | (hits["t"].view(np.uint32) != hits_loose["t"].view(np.uint32))
+    assert differ.sum() <= 2, int(differ.sum())
+    entered, entered_loose = int(ctr[:, 1].sum()), int(ctr_loose[:, 1].sum())
+    assert entered < 0.7 * entered_loose, (entered, entered_loose)
+
+
 @pytest.mark.parametrize("depth", [40, 100, 200])
 def test_wide_deep_tree_keeps_every_entry(pt, ora, wide_ctx, depth):
     """The wide traversal has no 64-entry limit to reproduce: on a vine-shaped BLAS deeper than the
