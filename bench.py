@@ -398,14 +398,14 @@ def main():
                          "visits_per_ray": {"interior": csum[0] / n_rays, "tlas_leaves": csum[1] / n_rays, "triangles": csum[2] / n_rays},
                          "levels": {"hbm_peak": HBM_PEAK_GBS, "hbm_bytes": streamed_bytes, "gather_ceiling": GATHER_CEILING_GBS, "gather_bytes": scene_bytes,
                                     "least_time_ms": least_ms},
-                         "hbm_only": {"achieved": achieved, "peak": HBM_PEAK_GBS, "frac": achieved / HBM_PEAK_GBS},
+                         "hbm_only": {"achieved": achieved, "hbm_peak": HBM_PEAK_GBS, "ratio_to_hbm_peak": achieved / HBM_PEAK_GBS},
                          "hbm_streamed": split_line(kernel_ms, streamed_bytes, scene_bytes),
                          "binding": binding,
                          "note": "`achieved` = all algorithmic bytes over the kernel time.  `peak` is the rate at which the memory system could deliver those "
                                  "bytes at best: the ray / hit bytes (hbm_bytes) at the HBM peak plus the node / triangle / instance bytes (gather_bytes), "
                                  "which are L2 / MALL resident (traffic << algorithmic bytes), at the measured ceiling for dependent gathers from such a table "
                                  "(tools/ubench/gather_shapes.hip, profiles/) - so frac cannot exceed 1.  hbm_only is the same bytes against the HBM peak alone "
-                                 "(the figure of earlier rounds; it passes 1 once the caches serve the scene faster than HBM could).  `binding` "
+                                 "(a ratio, not a roofline fraction: it passes 1 once the caches serve the scene faster than HBM could).  `binding` "
                                  "(rocprofv3 counters of this command, profiles/) names what limits the kernel"},
             "trace_modes": modes,
             "cpu_baseline": cpu,
