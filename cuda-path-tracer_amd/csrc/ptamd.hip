@@ -9,7 +9,10 @@
 #include <cstring>
 #include <functional>
 #include <mutex>
+#include <new>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -785,16 +788,37 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
     for (uint32_t i = 0; i < d->tlas_node_count; ++i) {
         const pt_tlas_node &n = d->tlas_nodes[i];
         if (n.left_right != 0 || (i == 0 && d->tlas_node_count > 1)) continue;  // interior node, or the root's copy of a lone leaf
-        const ptw::Box loose{{n.min[0], n.min[1], n.min[2]}, {n.max[0], n.max[1], n.max[2]}};
-        const pt_geometry_instance &g = d->geometries[n.instance];
-        const pt_blas &blas = d->blases[g.blas_index];
-        if (tight_boxes && blas.node_count > 0) {
-            MeshTree mesh{{d->blas_nodes, leaf_ref.data()}, d->blas_nodes, tris.data(), blas.first_index};
-            inst_boxes.push_back(ptw::TightInstanceBox(mesh, blas.first_node, g.transform, loose));
-        } else {
-            inst_boxes.push_back(loose);
-        }
+        inst_boxes.push_back(ptw::Box{{n.min[0], n.min[1], n.min[2]}, {n.max[0], n.max[1], n.max[2]}});
         inst_ids.push_back(n.instance);
+    }
+    if (tight_boxes) {
+        // Six support searches per instance (≈ 35 µs for a 70 k-triangle mesh): shared among host threads when there
+        // are thousands of instances.  Every search reads the scene only and writes its own box.
+        auto clip = [&](size_t first, size_t step) {
+            for (size_t k = first; k < inst_boxes.size(); k += step) {
+                const pt_geometry_instance &g = d->geometries[inst_ids[k]];
+                const pt_blas &blas = d->blases[g.blas_index];
+                if (blas.node_count == 0) continue;
+                const MeshTree mesh{{d->blas_nodes, leaf_ref.data()}, d->blas_nodes, tris.data(), blas.first_index};
+                try {
+                    inst_boxes[k] = ptw::TightInstanceBox(mesh, blas.first_node, g.transform, inst_boxes[k]);
+                } catch (const std::bad_alloc &) {
+                    // the reference's box stays
+                }
+            }
+        };
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t workers = inst_boxes.size() < 512 ? 1 : std::min<size_t>(hw ? hw : 1, 16);
+        std::vector<std::thread> pool;
+        try {
+            for (size_t t = 1; t < workers; ++t) pool.emplace_back(clip, t, workers);
+        } catch (const std::system_error &) {
+            // no more threads to be had: the ones that started keep their shares, the rest is done here
+        }
+        const size_t started = pool.size() + 1;
+        clip(0, workers);
+        for (size_t t = started; t < workers; ++t) clip(t, workers);
+        for (std::thread &th : pool) th.join();
     }
     const ptw::TopLevel top = ptw::BuildTopLevel(inst_boxes.data(), uint32_t(inst_boxes.size()));
     struct TopTree {
