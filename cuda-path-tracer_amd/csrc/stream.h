@@ -553,6 +553,9 @@ constexpr uint32_t kNoRayBits = 0x7FC0DEADu;  // t_max bit pattern (a NaN no com
 #ifndef PT_VOTE_RARE
 #define PT_VOTE_RARE 8   // lanes that make an instance enter / level change round worth running
 #endif
+#ifndef PT_DRAIN_PRIO
+#define PT_DRAIN_PRIO 0  // wave priority (1-3) once the wave can no longer refill; 0: unchanged
+#endif
 #ifndef PT_VOTE_LEVEL
 #define PT_VOTE_LEVEL 12  // lanes that make a level change round worth running (8 / 12 / 16: 1.56 / 1.53 / 1.54 ms on the bench batch)
 #endif
@@ -610,6 +613,9 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform
     uint32_t dry = 0;                      // wave-uniform: cursors found empty
     bool exhausted = false;                // wave-uniform
+#if PT_DRAIN_PRIO
+    bool boosted = false;                  // wave-uniform
+#endif
 #ifdef PT_TRACE_STAMPS
     unsigned long long tstamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tstamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstamp_last)::"memory");
@@ -701,6 +707,14 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
             }
         }
         const bool can_refill = !(exhausted && pool_next >= pool_end);  // wave-uniform
+#endif
+#if PT_DRAIN_PRIO
+        // A wave that can no longer refill only has the ends of its longest rays left, and the launch ends with the
+        // last of them: from here on its instructions go before those of waves that still have rays to take.
+        if (!can_refill && !boosted) {
+            __builtin_amdgcn_s_setprio(PT_DRAIN_PRIO);
+            boosted = true;
+        }
 #endif
         PT_PHASE(ev, 7);
         PT_TSTAMP(5);
