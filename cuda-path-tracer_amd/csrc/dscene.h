@@ -125,7 +125,7 @@ struct DCamera {
 struct DScene {
     const DNode *nodes;
     const DNode4 *nodes4;         // the same trees collapsed to 4-wide nodes (trace mode 2)
-    const DInst *insts4;          // wide layout: one enter record per top-level entry (d.x: root of the entry's subtree in nodes4, d.w: instance)
+    const uint32_t *inst_root4;   // per instance: reference of its BLAS root in nodes4
     const DTri *tris;
     const DInst *insts;
     const DInstFwd *fwd;

@@ -782,76 +782,33 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
             }
         }
     };
-    // Where the boxes are clipped, an instance whose mesh fills its own box badly is also *opened*: the top level then
-    // holds up to four entries for it, one per subtree two levels below the root of its BLAS, each with the clipped
-    // world box of that subtree's triangles, and a ray enters the instance at that subtree.  The subtrees of an instance
-    // hold disjoint sets of triangles, so a ray meets every triangle it met before at most once; candidates of two
-    // entries of one instance compete by the recomputed world distance, as candidates of two instances do.
     const bool tight_boxes = !getenv("PTAMD_LOOSE_INSTANCE_BOXES");
-    const bool open_instances = tight_boxes && !getenv("PTAMD_WHOLE_INSTANCES");
-    const float kOpenInstanceAreaRatio = getenv("PTAMD_OPEN_RATIO") ? float(atof(getenv("PTAMD_OPEN_RATIO"))) : 0.8f;
-    struct Entry {
-        uint32_t instance, subroot;  // subroot: the binary BLAS node the entry starts at
-    };
-    struct LeafEntries {
-        int n = 0;
-        Entry e[4];
-        ptw::Box box[4];
-    };
-    std::vector<LeafEntries> per_leaf;
+    std::vector<ptw::Box> inst_boxes;
+    std::vector<uint32_t> inst_ids;
     for (uint32_t i = 0; i < d->tlas_node_count; ++i) {
         const pt_tlas_node &n = d->tlas_nodes[i];
         if (n.left_right != 0 || (i == 0 && d->tlas_node_count > 1)) continue;  // interior node, or the root's copy of a lone leaf
-        LeafEntries le;
-        le.n = 1;
-        le.e[0] = Entry{n.instance, d->blases[d->geometries[n.instance].blas_index].first_node};
-        le.box[0] = ptw::Box{{n.min[0], n.min[1], n.min[2]}, {n.max[0], n.max[1], n.max[2]}};
-        per_leaf.push_back(le);
+        inst_boxes.push_back(ptw::Box{{n.min[0], n.min[1], n.min[2]}, {n.max[0], n.max[1], n.max[2]}});
+        inst_ids.push_back(n.instance);
     }
     if (tight_boxes) {
-        // Six support searches per box (≈ 35 µs for a 70 k-triangle mesh): shared among host threads when there
-        // are thousands of instances.  Every search reads the scene only and writes its own entry.
+        // Six support searches per instance (≈ 35 µs for a 70 k-triangle mesh): shared among host threads when there
+        // are thousands of instances.  Every search reads the scene only and writes its own box.
         auto clip = [&](size_t first, size_t step) {
-            for (size_t k = first; k < per_leaf.size(); k += step) {
-                LeafEntries &le = per_leaf[k];
-                const pt_geometry_instance &g = d->geometries[le.e[0].instance];
+            for (size_t k = first; k < inst_boxes.size(); k += step) {
+                const pt_geometry_instance &g = d->geometries[inst_ids[k]];
                 const pt_blas &blas = d->blases[g.blas_index];
                 if (blas.node_count == 0) continue;
                 const MeshTree mesh{{d->blas_nodes, leaf_ref.data()}, d->blas_nodes, tris.data(), blas.first_index};
                 try {
-                    const ptw::Box whole = ptw::TightInstanceBox(mesh, blas.first_node, g.transform, le.box[0]);
-                    le.box[0] = whole;
-                    if (!open_instances || mesh.is_leaf(blas.first_node)) continue;
-                    uint32_t sub[4];
-                    int n = 0;
-                    for (uint32_t child : {mesh.left(blas.first_node), mesh.right(blas.first_node)}) {
-                        if (mesh.is_leaf(child)) {
-                            sub[n++] = child;
-                        } else {
-                            sub[n++] = mesh.left(child);
-                            sub[n++] = mesh.right(child);
-                        }
-                    }
-                    ptw::Box boxes[4];
-                    float area = 0.0f;
-                    for (int c = 0; c < n; ++c) {
-                        boxes[c] = ptw::TightInstanceBox(mesh, sub[c], g.transform, whole);
-                        area += ptw::HalfArea(boxes[c]);
-                    }
-                    // worth it when a ray crossing the instance's box is likely to miss all of the parts
-                    if (!(area <= kOpenInstanceAreaRatio * ptw::HalfArea(whole))) continue;
-                    le.n = n;
-                    for (int c = 0; c < n; ++c) {
-                        le.e[c] = Entry{le.e[0].instance, sub[c]};
-                        le.box[c] = boxes[c];
-                    }
+                    inst_boxes[k] = ptw::TightInstanceBox(mesh, blas.first_node, g.transform, inst_boxes[k]);
                 } catch (const std::bad_alloc &) {
-                    // what has been settled so far stays (at worst the reference's box, whole)
+                    // the reference's box stays
                 }
             }
         };
         const unsigned hw = std::thread::hardware_concurrency();
-        const size_t workers = per_leaf.size() < 512 ? 1 : std::min<size_t>(hw ? hw : 1, 16);
+        const size_t workers = inst_boxes.size() < 512 ? 1 : std::min<size_t>(hw ? hw : 1, 16);
         std::vector<std::thread> pool;
         try {
             for (size_t t = 1; t < workers; ++t) pool.emplace_back(clip, t, workers);
@@ -863,28 +820,22 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
         for (size_t t = started; t < workers; ++t) clip(t, workers);
         for (std::thread &th : pool) th.join();
     }
-    std::vector<Entry> entries;
-    std::vector<ptw::Box> entry_boxes;
-    for (const LeafEntries &le : per_leaf)
-        for (int c = 0; c < le.n; ++c) {
-            entries.push_back(le.e[c]);
-            entry_boxes.push_back(le.box[c]);
-        }
-    if (entries.size() >= kLeafBit) return Fail(ctx, PT_ERR_LIMIT, "too many top-level entries");
-    const ptw::TopLevel top = ptw::BuildTopLevel(entry_boxes.data(), uint32_t(entry_boxes.size()));
+    const ptw::TopLevel top = ptw::BuildTopLevel(inst_boxes.data(), uint32_t(inst_boxes.size()));
     struct TopTree {
         const ptw::TopLevel *t;
+        const uint32_t *ids;
         bool is_leaf(uint32_t i) const { return t->nodes[i].left == 0xFFFFFFFFu; }
         uint32_t left(uint32_t i) const { return t->nodes[i].left; }
         uint32_t right(uint32_t i) const { return t->nodes[i].right; }
         ptw::Box box(uint32_t i) const { return t->nodes[i].box; }
-        uint32_t leaf_ref(uint32_t i) const { return kLeafBit | t->nodes[i].item; }  // the entry's number
+        uint32_t leaf_ref(uint32_t i) const { return kLeafBit | ids[t->nodes[i].item]; }
     };
-    const uint32_t root_ref4 = top.nodes.empty() ? root_ref : ptw::Collapse(TopTree{&top}, 0u, nodes4);
-    std::unordered_map<uint32_t, uint32_t> subtree4;  // binary BLAS node -> reference of its collapsed subtree in nodes4
-    for (const Entry &e : entries)
-        if (d->blases[d->geometries[e.instance].blas_index].node_count > 0 && !subtree4.count(e.subroot))
-            subtree4[e.subroot] = ptw::Collapse(BlasTree{d->blas_nodes, leaf_ref.data()}, e.subroot, nodes4);
+    const uint32_t root_ref4 = top.nodes.empty() ? root_ref : ptw::Collapse(TopTree{&top, inst_ids.data()}, 0u, nodes4);
+    std::vector<uint32_t> blas_root4(d->blas_count, kNoRef);
+    for (uint32_t b = 0; b < d->blas_count; ++b)
+        if (d->blases[b].node_count > 0) blas_root4[b] = ptw::Collapse(BlasTree{d->blas_nodes, leaf_ref.data()}, d->blases[b].first_node, nodes4);
+    std::vector<uint32_t> inst_root4(d->geometry_count);
+    for (uint32_t i = 0; i < d->geometry_count; ++i) inst_root4[i] = blas_root4[d->geometries[i].blas_index];
 
     // ---- instances
     std::vector<DInst> insts(d->geometry_count);
@@ -908,16 +859,6 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
         f.n2 = make_float4(col(N, 2, 2), col(N, 3, 0), col(N, 3, 1), col(N, 3, 2));
         f.m = make_float4(g.total_area, __builtin_bit_cast(float, uint32_t(g.area_light_id)),
                           __builtin_bit_cast(float, uint32_t(g.triangle_sampler_index)), __builtin_bit_cast(float, uint32_t(g.material_id)));
-    }
-
-    // the wide layout's enter records, one per top-level entry: the instance's record with the entry's subtree as root
-    // and the instance's number in the last word
-    std::vector<DInst> insts4(entries.size());
-    for (size_t v = 0; v < entries.size(); ++v) {
-        insts4[v] = insts[entries[v].instance];
-        const auto it = subtree4.find(entries[v].subroot);
-        insts4[v].d.x = __builtin_bit_cast(float, it == subtree4.end() ? kNoRef : it->second);
-        insts4[v].d.w = __builtin_bit_cast(float, entries[v].instance);
     }
 
     // ---- materials, textures, images
@@ -1092,7 +1033,7 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
     UP(nodes, nodes);
     if (nodes4.empty()) nodes4.emplace_back();
     UP(nodes4, nodes4);
-    UP(insts4, insts4);
+    UP(inst_root4, inst_root4);
     UP(tris, tris);
     UP(insts, insts);
     UP(fwd, fwd);

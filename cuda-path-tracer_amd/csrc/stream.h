@@ -358,10 +358,8 @@ struct Traversal {
     // TLAS leaf: enter the instance (kernel/intersection.h:183-188, :37-50).
     PTD void op_enter(const DScene &S) {
         if (COUNT) ctr.tlas_leaves++;
-        // binary layout: the leaf names the instance; wide layout: it names a top-level entry (an instance, or one of
-        // the subtrees an opened instance is entered at), whose record carries the instance's number
-        const uint32_t entry = cur & 0x7FFFFFFFu;
-        const float4 *ip = reinterpret_cast<const float4 *>((WIDE ? S.insts4 : S.insts) + entry);
+        cur_inst = int(cur & 0x7FFFFFFFu);
+        const float4 *ip = reinterpret_cast<const float4 *>(S.insts + cur_inst);
         DInst in;
         in.a = ip[0];
         in.b = ip[1];
@@ -375,8 +373,7 @@ struct Traversal {
         lfound = false;
         base = sp;
         in_blas = true;
-        cur_inst = WIDE ? int(as_u(in.d.w)) : int(entry);
-        cur = as_u(in.d.x);
+        cur = WIDE ? S.inst_root4[cur_inst] : as_u(in.d.x);
         cur_mat = as_u(in.d.y);
         cur_type = as_u(in.d.z);
         tri_left = 0;
