@@ -60,9 +60,44 @@ def split_line(ms, streamed_bytes, scene_bytes):
             "scene_gather_achieved": scene, "scene_gather_ceiling": GATHER_CEILING_GBS, "scene_gather_frac": scene / GATHER_CEILING_GBS}
 
 
+def free_port():
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, child=None):
+    """Starts `n` fresh processes of this script, one per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), waits
+    for all of them, prints rank 0's JSON line and returns the exit status (non-zero if any rank failed).  The parent
+    makes no GPU call and imports no torch, so nothing that has touched the GPU is ever replaced or forked.
+    `child` overrides the command of a rank (tests)."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = (child or [sys.executable, "-u", os.path.abspath(__file__)]) + argv
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    line = None
+    for ln in out0.decode(errors="replace").splitlines():  # the last JSON object rank 0 printed
+        if ln.startswith("{") and ln.rstrip().endswith("}"):
+            line = ln
+    failed = [r for r, c in enumerate(codes) if c != 0]
+    if failed or line is None:
+        sys.stderr.write(f"bench.py: rank(s) {failed} failed (exit codes {codes})\n" if failed else "bench.py: rank 0 printed no JSON line\n")
+        return next((c for c in codes if c != 0), 1)
+    print(line, flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1, help="ranks of the job, one per GPU; started here unless a launcher (WORLD_SIZE set) already did")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", default="helmet")
@@ -78,6 +113,10 @@ def main():
                     help="how the spp leg is dealt out over ranks: iteration blocks of the whole frame, or all iterations of a band of rows")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` with no launcher around it: this process only starts the N ranks (before any GPU call)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
 
@@ -86,8 +125,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
     # PT_BENCH_BACKEND=gloo rehearses the N > 1 code path where the ranks cannot each have a GPU of their own
-    # (RCCL refuses two ranks on one device): ranks then share the visible GPUs and the collectives run on the host
-    backend = os.environ.get("PT_BENCH_BACKEND", "nccl")
+    # (RCCL refuses two ranks on one device): ranks then share the visible GPUs and the collectives run on the host.
+    # Chosen by itself when the machine shows fewer GPUs than ranks (device_count() does not initialise the GPU).
+    backend = os.environ.get("PT_BENCH_BACKEND") or ("nccl" if torch.cuda.device_count() >= world else "gloo")
     device_index = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)

@@ -8,6 +8,7 @@ as integer addresses (e.g. ``tensor.data_ptr()``); nothing here allocates GPU me
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
 import os
 
 import numpy as np
@@ -152,10 +153,14 @@ def _pil_decoder():
 
             from PIL import Image
 
-            key = (C.addressof(data.contents), n, want_channels)
+            # The loader asks twice per image (size query, then fill) and frees the file's bytes in between
+            # files, so the address of the bytes says nothing about their content: the entry that spans the two
+            # calls is keyed on a digest of the bytes and dropped as soon as the pixels have been copied out.
+            raw = C.string_at(data, n)
+            key = (hashlib.blake2b(raw, digest_size=16).digest(), n, want_channels)
             if key not in cache:
                 cache.clear()
-                img = Image.open(io.BytesIO(C.string_at(data, n)))
+                img = Image.open(io.BytesIO(raw))
                 if want_channels in (3, 4):
                     img = img.convert("RGB" if want_channels == 3 else "RGBA")
                 px = np.asarray(img, dtype=np.uint8)
@@ -166,6 +171,7 @@ def _pil_decoder():
                 if capacity < px.size:
                     return 2
                 C.memmove(pixels, px.ctypes.data, px.size)
+                cache.clear()
             return 0
         except Exception:  # noqa: BLE001 - an exception must not cross the C boundary
             return 1

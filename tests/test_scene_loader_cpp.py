@@ -249,3 +249,36 @@ def test_scene_loaded_in_cpp_renders_the_oracle_film(pt, ora, gpu_ctx, tmp_path)
     film = gpu_ctx.film_download(w, h)
     assert ref.mean() > 1e-3 and np.isfinite(film).all()
     assert np.array_equal(film.view(np.uint32), ref.view(np.uint32))
+
+
+def test_pil_decoder_keeps_files_apart_that_share_an_address_and_a_size(pt):
+    """The loader frees a file's bytes before it reads the next file, so two files of the same length can sit at
+    the same address one after the other: the decoder callback must still decode each from its own content."""
+    from PIL import Image
+
+    from cuda_path_tracer_amd.runtime import _pil_decoder
+
+    def bmp(value):
+        b = io.BytesIO()
+        Image.fromarray(np.full((4, 5, 3), value, np.uint8)).save(b, format="BMP")
+        return b.getvalue()
+
+    first, second = bmp(10), bmp(200)
+    assert len(first) == len(second)
+    decode = _pil_decoder()
+    slot = (C.c_uint8 * len(first))()  # one address for both files
+    w, h, c = C.c_int(), C.c_int(), C.c_int()
+    for data, value in ((first, 10), (second, 200)):
+        C.memmove(slot, data, len(data))
+        assert decode(None, slot, len(data), 3, C.byref(w), C.byref(h), C.byref(c), None, 0) == 0  # size query
+        assert (w.value, h.value, c.value) == (5, 4, 3)
+        px = (C.c_uint8 * 60)()
+        assert decode(None, slot, len(data), 3, C.byref(w), C.byref(h), C.byref(c), px, 60) == 0   # fill
+        assert set(px) == {value}
+    # a second size query of the same address with new content, without a fill in between
+    C.memmove(slot, first, len(first))
+    assert decode(None, slot, len(first), 3, C.byref(w), C.byref(h), C.byref(c), None, 0) == 0
+    C.memmove(slot, second, len(second))
+    px = (C.c_uint8 * 60)()
+    assert decode(None, slot, len(second), 3, C.byref(w), C.byref(h), C.byref(c), px, 60) == 0
+    assert set(px) == {200}

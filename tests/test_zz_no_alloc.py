@@ -14,7 +14,15 @@ def _hits(pt, gpu_ctx, devbuf, fn, rays_d, n):
     return out.download(pt.abi.HIT, n)
 
 
-def test_static_scratch_entry_point_equals_trace_closest(pt, gpu_ctx, devbuf, scene_factory):
+@pytest.fixture(params=[0, 2], ids=["binary", "four_wide"])
+def trace_mode(request, gpu_ctx):
+    """Both node layouts: each has its own kernel behind the entry point."""
+    gpu_ctx.set_trace_mode(request.param)
+    yield request.param
+    gpu_ctx.set_trace_mode(0)
+
+
+def test_static_scratch_entry_point_equals_trace_closest(pt, gpu_ctx, devbuf, scene_factory, trace_mode):
     hs = scene_factory("helmet", 128, 96, 5)
     gpu_ctx.upload(hs.desc())
     for n, seed in ((300000, 11), (70001, 12)):  # the second call is smaller and reuses the array's last contents
@@ -26,7 +34,7 @@ def test_static_scratch_entry_point_equals_trace_closest(pt, gpu_ctx, devbuf, sc
         assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
 
 
-def test_static_scratch_deep_stacks_use_the_static_spill_area(pt, gpu_ctx, devbuf):
+def test_static_scratch_deep_stacks_use_the_static_spill_area(pt, gpu_ctx, devbuf, trace_mode):
     """A vine-shaped BLAS 100 levels deep pushes the traversal stack far beyond its LDS part."""
     from conftest import make_vine_scene, rays_from_arrays
 
