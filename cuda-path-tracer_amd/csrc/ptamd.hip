@@ -294,6 +294,9 @@ int Validate(pt_ctx *ctx, const pt_scene_desc *d) {
                 return Fail(ctx, PT_ERR_INVALID, "TLAS node %u has bad children", i);
         }
     }
+    // A node may be the child of one node only: children that are shared make the structure a graph whose
+    // unfolding (the 4-wide collapse walks it as a tree) can be exponentially larger than the arrays.
+    std::vector<uint8_t> has_parent(d->blas_node_count, 0);
     for (uint32_t i = 0; i < d->blas_count; ++i) {
         const pt_blas &b = d->blases[i];
         if (b.node_count == 0) continue;
@@ -306,6 +309,11 @@ int Validate(pt_ctx *ctx, const pt_scene_desc *d) {
                     return Fail(ctx, PT_ERR_INVALID, "BLAS %u leaf %u exceeds its triangle range", i, k);
             } else if (n.first_primitive <= k || uint64_t(n.first_primitive) + 1 >= uint64_t(b.first_node) + b.node_count) {
                 return Fail(ctx, PT_ERR_INVALID, "BLAS %u node %u has bad children", i, k);
+            } else {
+                for (uint32_t c = n.first_primitive; c <= n.first_primitive + 1; ++c) {
+                    if (has_parent[c]) return Fail(ctx, PT_ERR_INVALID, "BLAS %u node %u is the child of more than one node", i, c);
+                    has_parent[c] = 1;
+                }
             }
         }
     }
@@ -650,8 +658,20 @@ int pt_camera_update(pt_ctx *ctx, const pt_camera *camera) {
     return PT_OK;
 }
 
+static int UploadScene(pt_ctx *ctx, const pt_scene_desc *d);
+
 int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
     if (!ctx) return PT_ERR_INVALID;
+    try {
+        return UploadScene(ctx, d);
+    } catch (const std::bad_alloc &) {  // nothing may be thrown across the C boundary
+        DeviceGuard guard(ctx->device);
+        FreeScene(ctx);
+        return Fail(ctx, PT_ERR_LIMIT, "out of host memory while re-packing the scene");
+    }
+}
+
+static int UploadScene(pt_ctx *ctx, const pt_scene_desc *d) {
     DeviceGuard guard(ctx->device);
     int st = Validate(ctx, d);
     if (st != PT_OK) return st;
@@ -791,6 +811,12 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
         inst_boxes.push_back(ptw::Box{{n.min[0], n.min[1], n.min[2]}, {n.max[0], n.max[1], n.max[2]}});
         inst_ids.push_back(n.instance);
     }
+    double scene_extent = 0.0;  // diagonal of the scene's root box
+    for (int a = 0; a < 3; ++a) {
+        const double e = double(d->tlas_nodes[0].max[a]) - double(d->tlas_nodes[0].min[a]);
+        if (e == e && e > 0.0 && e < 1e30) scene_extent += e * e;
+    }
+    scene_extent = std::sqrt(scene_extent);
     if (tight_boxes) {
         // Six support searches per instance (≈ 35 µs for a 70 k-triangle mesh): shared among host threads when there
         // are thousands of instances.  Every search reads the scene only and writes its own box.
@@ -801,7 +827,7 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *d) {
                 if (blas.node_count == 0) continue;
                 const MeshTree mesh{{d->blas_nodes, leaf_ref.data()}, d->blas_nodes, tris.data(), blas.first_index};
                 try {
-                    inst_boxes[k] = ptw::TightInstanceBox(mesh, blas.first_node, g.transform, inst_boxes[k]);
+                    inst_boxes[k] = ptw::TightInstanceBox(mesh, blas.first_node, g.transform, inst_boxes[k], scene_extent);
                 } catch (const std::bad_alloc &) {
                     // the reference's box stays
                 }

@@ -270,8 +270,11 @@ double MeshSupport(const Tree &tree, uint32_t root, const double dir[3], int bud
 // The world box of the transformed mesh (column-major 4x4 transform), widened by a rounding margin and clipped
 // to the reference's box: it contains every transformed triangle and never exceeds what the reference tests.
 // A ray that misses it cannot hit the instance, so skipping the instance changes no result.
+// `scene_extent` is the size of the scene's root box (its diagonal): the rounding of a world-space box test
+// grows with the distance the ray has travelled, not with the mesh's own coordinates, so for a small mesh near
+// the origin that is hit from across the scene the margin must follow the scene's scale.
 template <class Tree>
-Box TightInstanceBox(const Tree &tree, uint32_t root, const float *transform, const Box &reference_box) {
+Box TightInstanceBox(const Tree &tree, uint32_t root, const float *transform, const Box &reference_box, double scene_extent = 0.0) {
     Box r;
     for (int a = 0; a < 3; ++a) {
         const double row[3] = {double(transform[a]), double(transform[4 + a]), double(transform[8 + a])};
@@ -280,7 +283,7 @@ Box TightInstanceBox(const Tree &tree, uint32_t root, const float *transform, co
         const double lo = -MeshSupport(tree, root, neg) + double(transform[12 + a]);
         // a few units in the last place of the largest coordinate involved: the reference moves the ray into
         // object space instead, and the two roundings must not disagree about a triangle on the box's face
-        const double margin = 1e-5 * std::fmax(std::fmax(std::fabs(lo), std::fabs(hi)), hi - lo);
+        const double margin = std::fmax(1e-5 * std::fmax(std::fmax(std::fabs(lo), std::fabs(hi)), hi - lo), 1e-6 * scene_extent);
         r.mn[a] = std::fmax(float(lo - margin), reference_box.mn[a]);
         r.mx[a] = std::fmin(float(hi + margin), reference_box.mx[a]);
         if (!(r.mn[a] <= r.mx[a])) return reference_box;  // not finite, or clipped away: keep the reference's box

@@ -877,9 +877,23 @@ private:
             if (v.type != Json::Array || v.arr.size() < count) throw Exception("glTF: node transform with too few numbers");
             for (size_t k = 0; k < count; ++k) out[k] = float(v.arr[k].num);
         };
+        // A node that is met again below itself is a cycle: refused at once (the recursion never gets deeper than the
+        // file's node count, and never deeper than kMaxNodeDepth, so a damaged file ends in an Exception, not in a
+        // stack overflow).  A node shared by several parents is loaded once per parent, bounded by the total below.
+        constexpr int kMaxNodeDepth = 512;
+        std::vector<char> on_path(jnodes.size(), 0);
+        int node_depth = 0;
         std::function<int(int, const Mat4 &)> load_node = [&](int ni, const Mat4 &parent) {
             if (ni < 0 || size_t(ni) >= jnodes.size()) throw Exception("glTF: node index out of range");
-            if (nodes.size() > jnodes.size() * 64 + 4096) throw Exception("glTF: node hierarchy is not a tree");  // a cycle would recurse for ever
+            if (on_path[size_t(ni)]) throw Exception("glTF: node hierarchy has a cycle");
+            if (node_depth >= kMaxNodeDepth) throw Exception("glTF: node hierarchy deeper than 512 levels");
+            if (nodes.size() > jnodes.size() * 64 + 4096) throw Exception("glTF: node hierarchy is not a tree");
+            struct OnPath {
+                char &flag;
+                int &depth;
+                OnPath(char &f, int &d) : flag(f), depth(d) { flag = 1; ++depth; }
+                ~OnPath() { flag = 0; --depth; }
+            } guard(on_path[size_t(ni)], node_depth);
             const Json &n = jnodes[size_t(ni)];
             const Mat4 I = Mat4::Identity();
             Vec3 t{0, 0, 0}, s{1, 1, 1};

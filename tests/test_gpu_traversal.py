@@ -356,5 +356,19 @@ def test_upload_validation(pt, gpu_ctx, tiny_scene):
     bad.geometries = geo.ctypes.data
     with pytest.raises(pt.PtError, match="bad material"):
         gpu_ctx.upload(bad)
+    # a BLAS whose interior nodes share children is a graph, not a tree: refused (the 4-wide collapse would
+    # unfold it into exponentially many nodes)
+    nodes = arr["blas_nodes"].copy()
+    blases = arr["blases"]
+    b = next(i for i in range(len(blases)) if blases["node_count"][i] >= 7)
+    first, count = int(blases["first_node"][b]), int(blases["node_count"][b])
+    interior = [k for k in range(first, first + count) if nodes["primitive_count"][k] == 0]
+    assert len(interior) >= 2
+    k0, k1 = interior[0], interior[1]
+    nodes["first_primitive"][k0] = nodes["first_primitive"][k1]  # k0 now names k1's children as its own
+    bad = pt.abi.SceneDesc.from_buffer_copy(d)
+    bad.blas_nodes = nodes.ctypes.data
+    with pytest.raises(pt.PtError, match="more than one node|bad children"):
+        gpu_ctx.upload(bad)
     gpu_ctx.upload(d)  # and the good description still uploads
     del copy
