@@ -153,7 +153,7 @@ struct DebugIO {
 
 __global__ __launch_bounds__(64) void k_debug_view(DScene S, DebugParams p, float *image, uint8_t *rgba, uint32_t n, uint32_t *cursors, uint32_t cursor_count, uint2 *spill,
                                                    uint32_t spill_stride, DevStats *stats) {
-    LaneEvents ev;
+    LaneEvents ev = make_events(spill + size_t(blockIdx.x) * kWave, spill_stride);
     DebugIO io{S, p, image, rgba};
     __shared__ unsigned long long lds[kWaveLdsEntries];
     const auto stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);

@@ -88,8 +88,11 @@ __device__ unsigned long long g_wave_times[2 * 8192];
 #endif
 
 PTD void flush_events(DevStats *stats, const LaneEvents &ev) {
-    if (ev.spills) atomicAdd(&stats->spills, ev.spills);
-    if (ev.drops) atomicAdd(&stats->drops, ev.drops);
+    if ((threadIdx.x & 63u) == 0) {  // the wave's own adds to these two words come first in its program order
+        const uint32_t spills = atomicAdd(ev.wave, 0u), drops = atomicAdd(ev.wave + 1, 0u);
+        if (spills) atomicAdd(&stats->spills, spills);
+        if (drops) atomicAdd(&stats->drops, drops);
+    }
 #ifdef PT_PHASE_PROF
     for (int k = 0; k < 8; ++k) {
         if (ev.lane_rounds[k]) atomicAdd(&g_phase_prof[k], (unsigned long long)ev.lane_rounds[k]);
@@ -136,7 +139,7 @@ struct ClosestIO {
 template <bool COUNT, bool WIDE = false>
 __global__ __launch_bounds__(64, PT_QUERY_WAVES_PER_SIMD) void k_trace_closest(DScene S, const pt_ray *rays, uint32_t n, pt_hit *hits, uint32_t *cursors, uint32_t cursor_count,
                                                       uint2 *spill, uint32_t spill_stride, DevStats *stats, TraceCounters *counters) {
-    LaneEvents ev;
+    LaneEvents ev = make_events(spill + size_t(blockIdx.x) * kWave, spill_stride);
     ClosestIO<COUNT> io{S, rays, hits, counters};
     __shared__ unsigned long long lds[kWaveLdsEntries];
     const auto stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
@@ -173,7 +176,7 @@ struct AnyIO {
 template <bool WIDE = false, bool COUNT = false>
 __global__ __launch_bounds__(64) void k_trace_any(DScene S, const pt_ray *rays, uint32_t n, uint8_t *occluded, uint32_t *cursors, uint32_t cursor_count,
                                                   uint2 *spill, uint32_t spill_stride, DevStats *stats, TraceCounters *counters) {
-    LaneEvents ev;
+    LaneEvents ev = make_events(spill + size_t(blockIdx.x) * kWave, spill_stride);
     AnyIO<COUNT> io{rays, occluded, counters};
     __shared__ unsigned long long lds[kWaveLdsEntries];
     const auto stk = make_lane_stack(lds, spill + size_t(blockIdx.x) * kWave, spill_stride);
@@ -401,7 +404,7 @@ template <bool WIDE = false>
 __global__ __launch_bounds__(64, PT_EXTEND_WAVES_PER_SIMD) void k_extend(DScene S, PathState P, BounceCounters *cnt, int bounce, int width, int height, uint2 *spill,
                                                uint32_t spill_stride, DevStats *stats) {
     BounceCounters *bc = cnt + bounce;
-    LaneEvents ev;
+    LaneEvents ev = make_events(spill + size_t(blockIdx.x) * kWave, spill_stride);
     __shared__ uint32_t stage[kNumClasses * kStageCap];
     ExtendIO io{S, P, bc, bounce == 0 ? nullptr : P.ext_q[bounce & 1], width, height};
     io.stage = stage;
@@ -791,7 +794,7 @@ template <bool WIDE = false>
 __global__ __launch_bounds__(64, PT_SHADOW_WAVES_PER_SIMD) void k_shadow(DScene S, PathState P, BounceCounters *cnt, int bounce, uint2 *spill,
                                                uint32_t spill_stride, DevStats *stats) {
     BounceCounters *bc = cnt + bounce;
-    LaneEvents ev;
+    LaneEvents ev = make_events(spill + size_t(blockIdx.x) * kWave, spill_stride);
     ShadowIO io{P};
     constexpr int kDepth = WIDE ? kRenderLdsDepthWide : kRenderLdsDepth;
     __shared__ unsigned long long lds[wave_lds_entries<kDepth>()];

@@ -55,7 +55,7 @@ constexpr uint32_t kStaticWaves = 1024;
 constexpr size_t kStaticCursorBytes = size_t(kMaxQueryCursors) * kCursorStride * sizeof(uint32_t);
 constexpr size_t kStaticStatsOffset = kStaticCursorBytes;
 constexpr size_t kStaticSpillOffset = kStaticCursorBytes + 256;
-constexpr size_t kStaticSpillBytes = size_t(kStaticWaves) * kWave * kSpillDepth * sizeof(uint2);
+constexpr size_t kStaticSpillBytes = size_t(kStaticWaves) * kWave * kSpillRows * sizeof(uint2);
 constexpr size_t kStaticScratchBytes = kStaticSpillOffset + kStaticSpillBytes;  // 60 MiB + 16.25 KiB
 static_assert(sizeof(DevStats) <= 256, "the counters fit their slot");
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
@@ -407,7 +407,7 @@ hipError_t SyncAll(pt_ctx *ctx) {
 
 int EnsureLaneSpill(pt_ctx *ctx, pt_ctx::Lane &l) {
     if (l.spill) return PT_OK;
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&l.spill), size_t(ctx->spill_stride) * kSpillDepth * sizeof(uint2)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&l.spill), size_t(ctx->spill_stride) * kSpillRows * sizeof(uint2)));
     return PT_OK;
 }
 

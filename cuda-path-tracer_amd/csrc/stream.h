@@ -111,6 +111,7 @@ struct Traversal {
     uint32_t cur_mat, cur_type;  // of the instance being searched
     bool lfound;     // WIDE: the current instance has produced a candidate
     bool prov;       // WIDE, closest hit: `best` is still the winner's object-space distance (op_level)
+    bool unit_dir;   // WIDE: |d| = 1 within rounding, so a world-space distance is also a bound on the ray parameter
     int cur_inst;
     int sp, base;
     bool in_blas;
@@ -133,6 +134,7 @@ struct Traversal {
         hit.inst = -1;
         hit.prim = hit.mat = hit.type = 0xFFFFFFFFu;
         found = false;
+        unit_dir = fabsf(dot(d, d) - 1.0f) <= 1e-4f;
         if (COUNT) {
             ctr = TraceCounters{0, 0, 0, 0};
             tlas_interior = 0;
@@ -211,7 +213,7 @@ struct Traversal {
     // One interior node: both child boxes, near child next, far child pushed
     // (kernel/intersection.h:114-135, :203-226).
     template <class STK>
-    PTD void op_interior(const STK &stk, LaneEvents &ev, float4 na, float4 nb, float4 nc, float4 nd) {
+    PTD void op_interior(const STK &stk, const LaneEvents &ev, float4 na, float4 nb, float4 nc, float4 nd) {
         if (COUNT) {
             ctr.interior++;
             if (!in_blas) tlas_interior++;
@@ -264,16 +266,16 @@ struct Traversal {
                 if (depth == kRefStack - 1) {
                     stack_store(stk, sp, left_first ? rref : lref, left_first ? tr : tl, ev);
                     ++sp;
-                    ev.drops++;
+                    ev.drop();
                 } else {
-                    ev.drops += 2;
+                    ev.drop(2);
                 }
                 cur = kNoRef;
             } else if (hl || hr) {
                 if (depth < kRefStack) {
                     cur = hl ? lref : rref;
                 } else {
-                    ev.drops++;
+                    ev.drop();
                     cur = kNoRef;
                 }
             } else {
@@ -294,7 +296,7 @@ struct Traversal {
     }
     static PTD float comp(const float4 &v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
     template <class STK>
-    PTD void op_interior4(const STK &stk, LaneEvents &ev, const float4 (&q)[7]) {
+    PTD void op_interior4(const STK &stk, const LaneEvents &ev, const float4 (&q)[7]) {
         if (COUNT) {
             ctr.interior++;
             if (!in_blas) tlas_interior++;
@@ -349,7 +351,7 @@ struct Traversal {
                     stack_store(stk, sp, ref[j], as_f(key[j]), ev);
                     ++sp;
                 } else {
-                    ev.drops++;  // the physical stack is full: the subtree is lost (counted in pt_stats.stack_drops)
+                    ev.drop();  // the physical stack is full: the subtree is lost (counted in pt_stats.stack_drops)
                 }
             }
         }
@@ -459,7 +461,10 @@ struct Traversal {
     // with EXACT_T, otherwise only for a hit so close to the origin that the recomputed distance could
     // come out negative, which the reference reports as a miss.
     static constexpr float kWideBoundMargin = 2.44140625e-4f;  // 2^-12
-    PTD float wide_bound() const { return best + fabsf(best) * kWideBoundMargin; }  // FLT_MAX stays "no bound" (+inf)
+    // `best` is a distance along the ray, dot(p - o, d) = t * |d|^2, and bounds the ray parameter t only for unit
+    // directions (pt_ray does not require them): any other ray searches every instance unbounded, as the
+    // reference does.
+    PTD float wide_bound() const { return unit_dir ? best + fabsf(best) * kWideBoundMargin : __builtin_inff(); }  // FLT_MAX stays "no bound" (+inf)
     PTD float world_distance(const DScene &S, uint32_t rec, float u, float v, int inst) const {
         const V3 lp = tri_point(S.tris, rec, u, v);
         const float4 *fp = reinterpret_cast<const float4 *>(S.fwd + inst);
@@ -603,7 +608,7 @@ PTD bool fetch_rays(const WorkFeed &feed, uint32_t n, uint32_t &dry, uint32_t &b
 }
 
 template <int MODE, bool COUNT, bool WIDE = false, class IO, class STK>
-PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed, const STK &stk, LaneEvents &ev) {
+PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed, const STK &stk, const LaneEvents &ev) {
     Traversal<MODE, COUNT, STK::kDepth, WIDE> tr;
     tr.cur = kNoRef;
     tr.in_blas = false;

@@ -47,6 +47,9 @@ constexpr int kRenderLdsDepth = PT_RENDER_LDS_DEPTH;
 constexpr int kRenderLdsDepthWide = PT_RENDER_LDS_DEPTH_WIDE;
 constexpr int kRefStack = 64;  // capacity of each of the reference's two stacks
 constexpr int kSpillDepth = 2 * kRefStack - (kLdsDepth < kRenderLdsDepth ? kLdsDepth : kRenderLdsDepth);  // sized for the shallower LDS part
+// The spill area has one more row than that: the first entry of a wave's share of it holds the wave's two
+// counters of rare events (LaneEvents).
+constexpr int kSpillRows = kSpillDepth + 1;
 constexpr int kWave = 64;
 
 enum { MODE_CLOSEST = 0, MODE_ANY = 1 };
@@ -94,11 +97,17 @@ struct TraceCounters {  // per-ray visit counts, filled only by the counting var
     uint32_t interior, tlas_leaves, tris, blas_leaves;
 };
 
-struct LaneEvents {  // rare events, flushed to the context's statistics by the caller
-    uint32_t spills = 0, drops = 0;
+// Rare events (an entry stored beyond the LDS part of the stack, a push dropped like the reference's full
+// stack drops it) are counted per wave in global memory, not in registers: two words in the extra row of the
+// wave's share of the spill area, zeroed by the wave when it starts and added to the context's statistics when
+// it ends (flush_events).  Counters in registers are carried around the box-test loop as eight copies per round.
+struct LaneEvents {
+    uint32_t *wave = nullptr;  // {spills, drops} of this wave
+    PTD void spill() const { atomicAdd(wave, 1u); }
+    PTD void drop(uint32_t n = 1) const { atomicAdd(wave + 1, n); }
 #ifdef PT_PHASE_PROF
     // diagnostic build only: per phase, rounds this lane took part in / rounds the wave ran
-    uint32_t lane_rounds[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wave_rounds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    mutable uint32_t lane_rounds[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wave_rounds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 };
 
@@ -114,14 +123,21 @@ struct LaneEvents {  // rare events, flushed to the context's statistics by the 
 
 // One 8-byte record per entry: node reference in the low word, box entry distance in the high.
 template <class STK>
-PTD void stack_store(const STK &s, int sp, uint32_t ref, float t, LaneEvents &ev) {
+PTD void stack_store(const STK &s, int sp, uint32_t ref, float t, const LaneEvents &ev) {
     const unsigned long long v = ((unsigned long long)as_u(t) << 32) | ref;
     if (__builtin_expect(sp < STK::kDepth, 1)) {
         s.lds[sp * kWave] = v;
     } else {
         s.spill[size_t(sp - STK::kDepth) * s.stride] = v;
-        ev.spills++;
+        ev.spill();
     }
+}
+// The wave's event counters: `spill_base` is the wave's first column of the spill area.  Called by all lanes.
+PTD LaneEvents make_events(uint2 *spill_base, uint32_t stride) {
+    LaneEvents ev;
+    ev.wave = reinterpret_cast<uint32_t *>(spill_base + size_t(kSpillDepth) * stride);
+    if ((threadIdx.x & 63u) == 0) *reinterpret_cast<uint2 *>(ev.wave) = make_uint2(0u, 0u);
+    return ev;
 }
 template <class STK>
 PTD uint2 stack_load(const STK &s, int sp) {

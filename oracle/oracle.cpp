@@ -26,6 +26,7 @@
 #include <numeric>
 #include <queue>
 #include <thread>
+#include <string>
 #include <vector>
 
 #include "../include/ptamd.h"
@@ -188,6 +189,10 @@ struct Counters {
     uint64_t tlas_interior = 0;  // the TLAS's share of `interior`
     uint32_t drops = 0;        // pushes dropped at depth 64
     uint32_t max_depth = 0;    // deepest stack seen (either level)
+    // when set: the ray's traversal as a string of steps (ora_trace_ops), one character per step:
+    // B interior node expanded, T triangle tested, E instance entered, L instance left / ray finished,
+    // C stack entry popped and skipped because its box starts beyond the best hit
+    std::string *ops = nullptr;
 };
 
 enum Mode { CLOSEST, ANY };
@@ -218,7 +223,10 @@ static bool IntersectBLAS(const Scene &scene, const pt_geometry_instance &geomet
         StackItem cur = stack.Pop();
         const pt_bvh_node &node = nodes[cur.node_index];
         if (mode == CLOSEST) {
-            if (cur.aabb_time >= best_time) continue;
+            if (cur.aabb_time >= best_time) {
+                if (ctr && ctr->ops) ctr->ops->push_back('C');
+                continue;
+            }
         }
         if (node.primitive_count > 0) {
             if (ctr) ctr->blas_leaves++;
@@ -232,6 +240,7 @@ static bool IntersectBLAS(const Scene &scene, const pt_geometry_instance &geomet
                 vec2 bary;
                 float time;
                 if (ctr) ctr->tris++;
+                if (ctr && ctr->ops) ctr->ops->push_back('T');
                 if (!IntersectTriangle(local_ray, p0, p1, p2, bary, time, t_max)) continue;
                 bool take = (mode == CLOSEST) ? (time < best_time) : true;
                 if (take) {
@@ -249,6 +258,7 @@ static bool IntersectBLAS(const Scene &scene, const pt_geometry_instance &geomet
             }
         } else {
             if (ctr) ctr->interior++;
+            if (ctr && ctr->ops) ctr->ops->push_back('B');
             uint32_t left = node.first_primitive;
             uint32_t right = left + 1;
             float left_time, right_time;
@@ -309,13 +319,18 @@ static bool IntersectScene(const Scene &scene, const Ray &ray, Intersection &int
         StackItem cur = stack.Pop();
         const pt_tlas_node &node = nodes[cur.node_index];
         if (mode == CLOSEST) {
-            if (cur.aabb_time >= best_time) continue;
+            if (cur.aabb_time >= best_time) {
+                if (ctr && ctr->ops) ctr->ops->push_back('C');
+                continue;
+            }
         }
         if (node.left_right == 0u) {
             if (ctr) ctr->tlas_leaves++;
+            if (ctr && ctr->ops) ctr->ops->push_back('E');
             const pt_geometry_instance &geometry = scene.geometries[node.instance];
             Intersection temp;
             bool hit = IntersectBLAS<mode>(scene, geometry, ray, temp, t_max, ctr);
+            if (ctr && ctr->ops) ctr->ops->push_back('L');
             temp.geometry_id = int(node.instance);
             if (mode == CLOSEST) {
                 if (temp.time < best_time && hit) {
@@ -329,6 +344,7 @@ static bool IntersectScene(const Scene &scene, const Ray &ray, Intersection &int
             }
         } else {
             if (ctr) { ctr->interior++; ctr->tlas_interior++; }
+            if (ctr && ctr->ops) ctr->ops->push_back('B');
             uint32_t left = node.left_right & 0xFFFFu;
             uint32_t right = node.left_right >> 16;
             float left_time, right_time;
@@ -1739,6 +1755,29 @@ int ora_trace_closest(const pt_scene_desc *desc, const pt_ray *rays, size_t n, p
         }
     }
     return 0;
+}
+// The steps of each ray's closest-hit traversal (Counters::ops), for scheduling studies of the device kernel:
+// ray i's steps are out[offsets[i] .. offsets[i + 1]); every ray ends with an 'L' (a ray that misses the scene's
+// box is that 'L' alone).  Returns the number of bytes needed; nothing past `capacity` is written.
+size_t ora_trace_ops(const pt_scene_desc *desc, const pt_ray *rays, size_t n, char *out, size_t capacity, uint64_t *offsets) {
+    Scene scene = make_scene(desc);
+    std::string ops;
+    size_t total = 0;
+    for (size_t i = 0; i < n; ++i) {
+        Ray r{{rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]}, {rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]}};
+        Counters c;
+        ops.clear();
+        c.ops = &ops;
+        Intersection is;
+        IntersectScene<CLOSEST>(scene, r, is, rays[i].tmax, &c);
+        ops.push_back('L');
+        offsets[i] = total;
+        for (size_t k = 0; k < ops.size(); ++k)
+            if (total + k < capacity) out[total + k] = ops[k];
+        total += ops.size();
+    }
+    offsets[n] = total;
+    return total;
 }
 // The constants this file uses in place of src/math/constants.h, in that header's order (those it has a use for; 0 otherwise).
 void ora_constants(float out[9]) {
