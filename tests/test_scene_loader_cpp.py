@@ -210,7 +210,9 @@ def test_malformed_files_end_in_an_error_not_a_crash(pt, tmp_path):
     damaged(lambda g: g.pop("scenes"), "scenes")
     damaged(lambda g: g.update(scene=2), "scene index")
     damaged(lambda g: g["scenes"][0].update(nodes=[5]), "node index")
-    damaged(lambda g: g["nodes"][0].update(children=[0]), "not a tree")
+    damaged(lambda g: g["nodes"][0].update(children=[0]), "has a cycle")  # refused on the first revisit, not after thousands of frames
+    damaged(lambda g: (g["nodes"].extend({"children": [k + 1]} for k in range(len(g["nodes"]), len(g["nodes"]) + 3000)), g["nodes"][-1].pop("children"),
+                       g["nodes"][0].update(children=[len(good["nodes"])])), "deeper than")  # a 3000-level chain
     damaged(lambda g: g["nodes"][0].update(matrix=[1, 0, 0]), "too few numbers")
     # numbers that no integer can hold (their conversion would be undefined behaviour) are refused by name
     damaged(lambda g: g["accessors"][2].update(count=1e40), "'count' is not a usable whole number")

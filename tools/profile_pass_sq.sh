@@ -3,7 +3,7 @@
 set -e -o pipefail
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-OUT=gpurun_out/sqpass
+OUT=gpurun_out/sqpass${PT_TRACE_MODE:-0}
 rm -rf $OUT && mkdir -p $OUT
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/a -- python3 tools/queue_sizes.py 8 > $OUT/a.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_WAIT_ANY SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_FLAT --output-format csv -d $OUT/b -- python3 tools/queue_sizes.py 8 > $OUT/b.log 2>&1
@@ -12,7 +12,7 @@ timeout -s KILL 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum T
 python3 - <<'PY'
 import csv, glob, collections
 for name in "abcd":
-    fs = glob.glob(f"gpurun_out/sqpass/{name}/vm/*_counter_collection.csv")
+    fs = glob.glob(f"gpurun_out/sqpass" + __import__("os").environ.get("PT_TRACE_MODE", "0") + f"/{name}/vm/*_counter_collection.csv")
     if not fs: continue
     rows = collections.OrderedDict()
     for r in csv.DictReader(open(fs[0])):

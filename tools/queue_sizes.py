@@ -13,6 +13,7 @@ hs = pt.SceneSpec.load(os.path.join(ROOT, "scenes", "helmet.npz")).build(width=W
 ctx = pt.Context(0)
 hs.update_device(ctx)
 ctx.integrator_init(W, H)
+ctx.set_trace_mode(int(os.environ.get("PT_TRACE_MODE", "0")))
 ctx.render_batch(W, H, 0, B)
 ctx.synchronize()
 st = ctx.stats()
