@@ -56,7 +56,7 @@ constexpr size_t kStaticCursorBytes = size_t(kMaxQueryCursors) * kCursorStride *
 constexpr size_t kStaticStatsOffset = kStaticCursorBytes;
 constexpr size_t kStaticSpillOffset = kStaticCursorBytes + 256;
 constexpr size_t kStaticSpillBytes = size_t(kStaticWaves) * kWave * kSpillRows * sizeof(uint2);
-constexpr size_t kStaticScratchBytes = kStaticSpillOffset + kStaticSpillBytes;  // 60 MiB + 16.25 KiB
+constexpr size_t kStaticScratchBytes = kStaticSpillOffset + kStaticSpillBytes;  // 60.5 MiB + 16.25 KiB
 static_assert(sizeof(DevStats) <= 256, "the counters fit their slot");
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 

@@ -447,12 +447,14 @@ int pt_trace_any_counted(pt_ctx *ctx, const pt_ray *rays_device, size_t n, uint8
 /* pt_trace_closest for callers that cannot allocate (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc): no counterpart in the reference.  The call allocates
  * nothing and creates no events: its scratch (work-feed cursors, event counters, traversal-stack
- * spill area for 1024 persistent waves) is a file-scope device array of 60 MiB + 16.25 KiB that every
+ * spill area for 1024 persistent waves) is a file-scope device array of 60.5 MiB + 16.25 KiB that every
  * GPU the library runs on holds until the process ends.  Results are those of pt_trace_closest, bit
  * for bit.  n > PT_STATIC_MAX_RAYS returns PT_ERR_LIMIT.  All calls on one GPU share that GPU's
  * array: calls that overlap on one GPU (two contexts, two streams) race; calls on one stream do not.
  * Stack spills / drops of these calls are not added to pt_stats.  Asynchronous on the context's
- * stream like pt_trace_closest.                                                               */
+ * stream like pt_trace_closest.  "Allocates nothing" is about the library's calls: in trace modes
+ * 2 / 3 the kernel behind it keeps a few spilled registers (under 64 bytes per lane) in the private
+ * segment that the HIP runtime provides to any kernel that declares one; trace modes 0 / 1 use none. */
 #define PT_STATIC_MAX_RAYS ((size_t)1 << 26)
 int pt_trace_closest_static(pt_ctx *ctx, const pt_ray *rays_device, size_t n, pt_hit *hits_device);
 /* Host-pointer conveniences (stage through device memory, synchronous). */
