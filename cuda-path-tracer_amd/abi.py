@@ -157,7 +157,8 @@ PTH_SYMBOLS = [
     "pth_scene_add_material", "pth_scene_add_texture1", "pth_scene_add_texture3", "pth_scene_add_image",
     "pth_scene_new_blas_index", "pth_scene_add_instance", "pth_scene_finalize", "pth_scene_finalize_device", "pth_scene_get_desc",
     "pth_scene_update_device", "pth_integrator_create", "pth_integrator_destroy", "pth_integrator_init",
-    "pth_integrator_resize", "pth_integrator_reset", "pth_integrator_render", "pth_debug_render", "pth_render_offscreen", "pth_checkpoint_read", "pth_save_png", "pth_save_hdr"]
+    "pth_integrator_resize", "pth_integrator_reset", "pth_integrator_render", "pth_debug_render", "pth_render_offscreen", "pth_checkpoint_read", "pth_save_png", "pth_save_hdr",
+    "pth_decode_image", "pth_decode_image_error"]
 
 # pth_image_decoder (include/ptamd_host.h)
 IMAGE_DECODER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
@@ -252,6 +253,8 @@ def load_library() -> C.CDLL:
         "pth_bvh_free": (None, [vp]),
         "pth_scene_create": (i32, [C.POINTER(vp)]),
         "pth_scene_load": (i32, [C.c_char_p, IMAGE_DECODER, vp, i32, i32, i32, C.POINTER(vp)]),
+        "pth_decode_image": (i32, [vp, C.POINTER(C.c_uint8), C.c_size_t, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_uint8), C.c_size_t]),
+        "pth_decode_image_error": (C.c_char_p, []),
         "pth_scene_destroy": (None, [vp]),
         "pth_scene_set_integrator": (i32, [vp, i32, i32]),
         "pth_scene_set_camera": (i32, [vp, fp, fp, fp, f32, i32, i32]),

@@ -194,12 +194,21 @@ class HostScene:
         self.max_depth, self.max_iterations = 4, 1000
 
     @classmethod
-    def load(cls, path: str, width: int = 0, height: int = 0, max_depth: int = 0, ctx: "Context" = None, decode_images: bool = True) -> "HostScene":
-        """Scene::LoadScene (scene.cpp:649-687) through the C++ front end: scene JSON, glTF, OBJ.  Images are
-        decoded by PIL through a callback.  The scene comes back finalised (on the GPU behind `ctx` when given)."""
+    def load(cls, path: str, width: int = 0, height: int = 0, max_depth: int = 0, ctx: "Context" = None, decode_images: bool = True,
+             decoder: str = "builtin") -> "HostScene":
+        """Scene::LoadScene (scene.cpp:649-687) through the C++ front end: scene JSON, glTF, OBJ.  Images are decoded by
+        the library's own JPEG / PNG decoder (`decoder="builtin"`, pth_decode_image) or by PIL through a callback
+        (`decoder="pil"`, any format PIL reads).  The scene comes back finalised (on the GPU behind `ctx` when given)."""
         lib = abi.load_library()
         h = C.c_void_p()
-        decoder = _pil_decoder() if decode_images else abi.IMAGE_DECODER()
+        if not decode_images:
+            decoder = abi.IMAGE_DECODER()
+        elif decoder == "pil":
+            decoder = _pil_decoder()
+        elif decoder == "builtin":
+            decoder = C.cast(lib.pth_decode_image, abi.IMAGE_DECODER)
+        else:
+            raise ValueError("decoder must be 'builtin' or 'pil'")
         _host_check(lib.pth_scene_load(os.fspath(path).encode(), decoder, None, int(width), int(height), int(max_depth), C.byref(h)))
         hs = cls(_handle=h)
         hs.finalize(ctx)

@@ -6,8 +6,8 @@
  *   headless_render <scene.json> <output prefix> [iterations] [samples per pass] [tile_rank tile_world]
  *
  * With the last two arguments only the rank's band of rows is rendered (pt_set_render_window), as one
- * rank of an image-tile sharded job would.  Scenes with image textures need a decoder callback, which
- * this example does not bring; it passes NULL.                                                       */
+ * rank of an image-tile sharded job would.  Image textures (the helmet scene's JPEGs) are decoded by
+ * the library's own decoder, pth_decode_image, handed to the loader as its callback.                 */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -30,7 +30,7 @@ int main(int argc, char **argv) {
     pt_ctx *ctx = NULL;
     if (pt_ctx_create(0, &ctx) != PT_OK) return fail("pt_ctx_create", ctx);
     pth_scene *scene = NULL;
-    if (pth_scene_load(argv[1], NULL, NULL, 0, 0, 0, &scene) != PT_OK) return fail("pth_scene_load", ctx);
+    if (pth_scene_load(argv[1], pth_decode_image, NULL, 0, 0, 0, &scene) != PT_OK) return fail("pth_scene_load", ctx);
     if (pth_scene_finalize_device(scene, ctx) != PT_OK) return fail("pth_scene_finalize_device", ctx);
     pt_scene_desc desc;
     if (pth_scene_get_desc(scene, &desc) != PT_OK) return fail("pth_scene_get_desc", ctx);

@@ -77,8 +77,8 @@ int pth_scene_update_device(pth_scene *scene, pt_ctx *ctx);
  * FACE_NORMALS de-indexing, T * Rx * Ry * Rz * S transforms).  The scene comes back filled but not
  * finalised: finish with pth_scene_finalize or pth_scene_finalize_device.  width / height /
  * max_depth > 0 override the file's values.
- * Image files (PATH textures, glTF images) are decoded by the caller's callback, because no image
- * decoder can be linked here; scenes without image textures may pass NULL.  The callback is called
+ * Image files (PATH textures, glTF images) are decoded by a callback: pth_decode_image below (this
+ * library's own JPEG / PNG decoder) or the caller's; scenes without image textures may pass NULL.  The callback is called
  * twice per image: first with pixels == NULL to report width, height and channel count, then with a
  * buffer of width*height*channels bytes to fill (8 bits per channel, rows top to bottom).
  * want_channels: 0 = as stored in the file, 3 = RGB, 4 = RGBA.  Non-zero return = failure.        */
@@ -86,6 +86,16 @@ typedef int (*pth_image_decoder)(void *user, const uint8_t *file_bytes, size_t n
                                  int *height, int *channels, uint8_t *pixels, size_t capacity);
 int pth_scene_load(const char *path, pth_image_decoder decode, void *user, int width, int height, int max_depth,
                    pth_scene **out);
+/* A pth_image_decoder of this library's own (host/image_decode.cpp), in place of the stb_image the reference decodes
+ * its textures with (image.cpp:58-103, gltf_model.cpp:96-152): baseline, extended-sequential and progressive
+ * Huffman-coded JPEG with 1 or 3 components of 8 bits (sampling factors 1 and 2, restart intervals), and PNG of every
+ * colour type and bit depth, interlaced or not (16-bit samples keep their high byte, palettes and tRNS are expanded).
+ * JPEG output is within 3 / 255 per channel of stb_image's and libjpeg's (inverse DCT in floating point, chroma of
+ * subsampled files interpolated with (3, 1) / 4 weights); PNG output is exact.  `user` is ignored.  Returns 0, or 1
+ * with the reason in pth_decode_image_error() (thread-local).                                                      */
+int pth_decode_image(void *user, const uint8_t *file_bytes, size_t n_bytes, int want_channels, int *width, int *height,
+                     int *channels, uint8_t *pixels, size_t capacity);
+const char *pth_decode_image_error(void);
 
 /* ---- PathIntegrator (kernel/integrators/path_trace.h:82-116) */
 int pth_integrator_create(pt_ctx *ctx, pth_integrator **out);

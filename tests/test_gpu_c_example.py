@@ -54,3 +54,36 @@ def test_c_program_renders_the_same_film_as_the_bindings(pt, gpu_ctx, tmp_path):
         assert (part[outside] == 0).all() and part[rows].any()
         total += part
     assert np.array_equal(total.view(np.uint32), expected.view(np.uint32))
+
+
+def test_c_program_loads_image_textures_with_the_library_decoder(pt, gpu_ctx, tmp_path):
+    """A scene with PATH textures and a glTF with embedded images, plus a JPEG of the helmet scene as a further
+    texture: the plain-C host decodes them with pth_decode_image and renders the film the bindings render."""
+    import json
+
+    from test_scene_loader_cpp import _textured_scene
+
+    path = _textured_scene(tmp_path)
+    spec = pt.SceneSpec.load(os.path.join(ROOT, "scenes", "helmet.npz"))
+    jpeg = next(spec.arrays[o["data"]].tobytes() for o in spec.ops if o["op"] == "image" and o.get("encoded"))
+    (tmp_path / "helmet_albedo.jpg").write_bytes(jpeg)
+    scene = json.loads(open(path).read())
+    first = next(iter(scene["materials"]))
+    scene["materials"]["zz_jpeg"] = {"TYPE": "lambertian", "ALBEDO": {"PATH": "helmet_albedo.jpg"}}
+    scene["objects"].append({"TYPE": "obj", "PATH": "quad.obj", "MATERIAL": "zz_jpeg", "TRANS": [-0.6, 0.2, 0.1], "ROTAT": [0, 20, 0], "SCALE": [0.8, 0.8, 0.8]})
+    path2 = str(tmp_path / "textured_jpeg.json")
+    open(path2, "w").write(json.dumps(scene))
+    assert first
+    iterations = 4
+    _run(path2, tmp_path / "tex", iterations, 2)
+    film, done = pt.checkpoint_read(str(tmp_path / "tex.film"))
+    assert done == iterations
+    hs = pt.HostScene.load(path2, ctx=gpu_ctx)  # the same loader and decoder through the bindings
+    w, h = hs.width, hs.height
+    gpu_ctx.upload(hs.desc())
+    gpu_ctx.integrator_init(w, h)
+    for it in range(iterations):
+        gpu_ctx.render(w, h, it)
+    expected = gpu_ctx.film_download(w, h)
+    assert expected.mean() > 1e-3
+    assert np.array_equal(film.view(np.uint32), expected.view(np.uint32))

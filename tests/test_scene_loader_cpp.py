@@ -230,8 +230,21 @@ def test_reference_scene_files_load_to_the_cooked_scenes(pt, name, rel):
     src = os.path.join("/root/reference/Scenes", rel)
     if not os.path.exists(src):
         pytest.skip("reference scene files are not on this machine")
-    cooked = pt.SceneSpec.load(os.path.join(ROOT, "scenes", name + ".npz")).build(width=64, height=48)
-    _assert_same(_everything(pt.HostScene.load(src, width=64, height=48)), _everything(cooked))
+    cooked = _everything(pt.SceneSpec.load(os.path.join(ROOT, "scenes", name + ".npz")).build(width=64, height=48))
+    _assert_same(_everything(pt.HostScene.load(src, width=64, height=48, decoder="pil")), cooked)  # the cook step decoded with PIL
+    # the library's own decoder: the same scene, JPEG texels within 3 / 255 of PIL's (all else byte for byte)
+    own = _everything(pt.HostScene.load(src, width=64, height=48))
+    assert own.keys() == cooked.keys()
+    texels = 0
+    for k, v in own.items():
+        if k.startswith("images") and isinstance(v, np.ndarray):
+            assert v.shape == cooked[k].shape and np.abs(v - cooked[k]).max() <= 3.0 / 255.0 + 1e-6, k
+            texels += v.size
+        elif isinstance(v, np.ndarray):
+            assert np.ascontiguousarray(v).tobytes() == np.ascontiguousarray(cooked[k]).tobytes(), k
+        else:
+            assert v == cooked[k], k
+    assert texels > 0 or name != "helmet"
 
 
 @pytest.mark.gpu
