@@ -61,14 +61,16 @@ PTD V3 heat_map_color(int depth, int max_depth) {  // debug.cu:42-49
 // Stream i = path-slot order (8x8 pixel tiles, one per wave), so a wave's rays form a bundle.
 struct DebugIO {
     static constexpr bool kExactDistance = true;
+    static constexpr bool kStageCull = false;  // a pixel whose ray misses the scene is coloured by done() like any other
     const DScene &S;
     DebugParams p;
     float *image;    // W*H*3, may be null
     uint8_t *rgba;   // W*H*4, may be null
 
-    PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax, uint32_t &) const {
+    PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax, uint32_t &tag) const {
         int x, y;
         if (!slot_to_pixel(i, p.width, p.height, x, y)) return false;
+        tag = i;
         const DCamera &c = S.camera;  // SpawnCameraRay with sample (0.5, 0.5), kernel/camera.h:10-22
         const float fx = ((float(x) + 0.5f) - 0.5f * float(c.res_x)) * c.px;
         const float fy = ((float(y) + 0.5f) - 0.5f * float(c.res_y)) * c.py;
@@ -122,7 +124,7 @@ struct DebugIO {
         return splat(0.0f);
     }
 
-    PTD void done(uint32_t i, uint32_t, const Traversal<MODE_CLOSEST, true> &tr, bool hit) const {
+    PTD void done(uint32_t i, const Traversal<MODE_CLOSEST, true> &tr, bool hit) const {
         int x, y;
         slot_to_pixel(i, p.width, p.height, x, y);
         const size_t index = size_t(x) + size_t(p.width) * size_t(y);

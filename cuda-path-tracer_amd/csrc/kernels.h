@@ -105,28 +105,36 @@ PTD void flush_events(DevStats *stats, const LaneEvents &ev) {
 template <bool COUNT>
 struct ClosestIO {
     static constexpr bool kExactDistance = true;
+    static constexpr bool kStageCull = true;
     const DScene &S;
     const pt_ray *rays;
     pt_hit *hits;
     TraceCounters *counters;
-    PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax, uint32_t &) const {
+    PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax, uint32_t &tag) const {
         const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
         const float4 ro = rp[0], rd = rp[1];
         o = mk3(ro.x, ro.y, ro.z);
         d = mk3(rd.x, rd.y, rd.z);
         tmax = rd.w;
+        tag = i;
         return true;
     }
+    // the record is not read again by this launch: stored past the caches' retention (2.5 % of the launch time
+    // against plain stores, measured on the bench's batch)
+    PTD void store(uint32_t i, float t, float u, float v, int prim, int inst, int mat) const {
+        v4f *np = reinterpret_cast<v4f *>(hits + i);
+        __builtin_nontemporal_store(v4f{t, u, v, as_f(uint32_t(prim))}, np);
+        __builtin_nontemporal_store(v4f{as_f(uint32_t(inst)), as_f(uint32_t(mat)), 0.0f, 0.0f}, np + 1);
+    }
     template <class TR>
-    PTD void done(uint32_t i, uint32_t, const TR &tr, bool hit) const {
-        const int prim = hit ? int(tr.hit.prim) : -1, mat = hit ? int(tr.hit.mat) : -1;
-        float4 *hp = reinterpret_cast<float4 *>(hits + i);
-        // the record is not read again by this launch: stored past the caches' retention (2.5 % of the launch time
-        // against plain stores, measured on the bench's batch)
-        v4f *np = reinterpret_cast<v4f *>(hp);
-        __builtin_nontemporal_store(v4f{hit ? tr.hit.t : -1.0f, hit ? tr.hit.u : 0.0f, hit ? tr.hit.v : 0.0f, as_f(uint32_t(prim))}, np);
-        __builtin_nontemporal_store(v4f{as_f(uint32_t(hit ? tr.hit.inst : -1)), as_f(uint32_t(mat)), 0.0f, 0.0f}, np + 1);
+    PTD void done(uint32_t i, const TR &tr, bool hit) const {
+        if (hit) store(i, tr.hit.t, tr.hit.u, tr.hit.v, int(tr.hit.prim), tr.hit.inst, int(tr.hit.mat));
+        else store(i, -1.0f, 0.0f, 0.0f, -1, -1, -1);
         if (COUNT) counters[i] = tr.ctr;
+    }
+    PTD void miss(uint32_t i, float) const {
+        store(i, -1.0f, 0.0f, 0.0f, -1, -1, -1);
+        if (COUNT) counters[i] = TraceCounters{0, 0, 0, 0};
     }
     PTD bool has_pending() const { return false; }
     PTD void flush() const {}
@@ -152,21 +160,27 @@ __global__ __launch_bounds__(64, PT_QUERY_WAVES_PER_SIMD) void k_trace_closest(D
 template <bool COUNT>
 struct AnyIO {
     static constexpr bool kExactDistance = true;
+    static constexpr bool kStageCull = true;
     const pt_ray *rays;
     uint8_t *occluded;
     TraceCounters *counters;
-    PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax, uint32_t &) const {
+    PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax, uint32_t &tag) const {
         const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
         const float4 ro = rp[0], rd = rp[1];
         o = mk3(ro.x, ro.y, ro.z);
         d = mk3(rd.x, rd.y, rd.z);
         tmax = rd.w;
+        tag = i;
         return true;
     }
     template <class TR>
-    PTD void done(uint32_t i, uint32_t, const TR &tr, bool hit) const {
+    PTD void done(uint32_t i, const TR &tr, bool hit) const {
         occluded[i] = hit ? 1 : 0;
         if (COUNT) counters[i] = tr.ctr;
+    }
+    PTD void miss(uint32_t i, float) const {
+        occluded[i] = 0;
+        if (COUNT) counters[i] = TraceCounters{0, 0, 0, 0};
     }
     PTD bool has_pending() const { return false; }
     PTD void flush() const {}
@@ -305,6 +319,7 @@ __global__ __launch_bounds__(64) void k_generate(DScene S, PathState P, BounceCo
 // throughput * 0, path_trace.cu:351-356: a no-op unless the throughput is not finite).
 struct ExtendIO {
     static constexpr bool kExactDistance = false;  // a path keeps (instance, u, v, record) of its hit, not the distance
+    static constexpr bool kStageCull = true;
     const DScene &S;
     const PathState &P;
     BounceCounters *bc;
@@ -333,17 +348,21 @@ struct ExtendIO {
         return true;
     }
     PTD bool has_pending() const { return pending; }
+    // a miss ends the path on the spot: it enters no class queue, so no hit record is kept
+    PTD void miss(uint32_t slot, float tmax) const {
+        if (tmax > FLT_MAX) {  // the black environment adds throughput * 0: NaN iff the throughput is not finite
+            const float4 t = P.thr[slot];
+            float4 a = P.accum[slot];
+            a.x += t.x * 0.0f;
+            a.y += t.y * 0.0f;
+            a.z += t.z * 0.0f;
+            P.accum[slot] = a;
+        }
+    }
     template <class TR>
-    PTD void done(uint32_t, uint32_t slot, const TR &tr, bool hit) {
-        if (!hit) {  // a miss ends the path here: it enters no class queue, so no hit record is kept
-            if (tr.t_max > FLT_MAX) {  // the black environment adds throughput * 0: NaN iff the throughput is not finite
-                const float4 t = P.thr[slot];
-                float4 a = P.accum[slot];
-                a.x += t.x * 0.0f;
-                a.y += t.y * 0.0f;
-                a.z += t.z * 0.0f;
-                P.accum[slot] = a;
-            }
+    PTD void done(uint32_t slot, const TR &tr, bool hit) {
+        if (!hit) {
+            miss(slot, tr.t_max);
             return;
         }
         P.hit[slot] = make_float4(as_f(uint32_t(tr.hit.inst)), tr.hit.u, tr.hit.v, as_f(tr.hit.rec));
@@ -762,6 +781,7 @@ __global__ __launch_bounds__(64) void k_shade(DScene S, PathState P, BounceCount
 // t_max = dist - 1e-4; an unoccluded sample adds its contribution to the path's radiance.
 struct ShadowIO {
     static constexpr bool kExactDistance = true;
+    static constexpr bool kStageCull = true;
     const PathState &P;
     PTD bool load(uint32_t i, V3 &o, V3 &d, float &tmax, uint32_t &tag) {
         const uint32_t slot = P.sh_q[i];
@@ -772,15 +792,17 @@ struct ShadowIO {
         tmax = so.w;
         return true;
     }
-    template <class TR>
-    PTD void done(uint32_t, uint32_t slot, const TR &, bool occluded) const {
-        if (occluded) return;
+    PTD void miss(uint32_t slot, float) const {  // nothing between the surface and the light
         const float4 contrib = P.sh_c[slot];
         float4 a = P.accum[slot];
         a.x += contrib.x;
         a.y += contrib.y;
         a.z += contrib.z;
         P.accum[slot] = a;
+    }
+    template <class TR>
+    PTD void done(uint32_t slot, const TR &, bool occluded) const {
+        if (!occluded) miss(slot, 0.0f);
     }
     PTD bool has_pending() const { return false; }
     PTD void flush() const {}

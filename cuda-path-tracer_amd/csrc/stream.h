@@ -124,7 +124,7 @@ struct Traversal {
     uint32_t tlas_interior;  // the TLAS's share of ctr.interior (counting variants only)
 
     // Returns false when the ray misses the scene's root box (kernel/intersection.h:162).
-    PTD bool begin(const DScene &S, V3 origin, V3 dir, float tmax) {
+    PTD bool begin(const DScene &S, V3 origin, V3 dir, float tmax, bool root_tested = false) {
         o = origin;
         d = dir;
         t_max = tmax;
@@ -141,7 +141,7 @@ struct Traversal {
         }
         iw = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         float t;
-        if (!slab(o, iw, S.root_min[0], S.root_min[1], S.root_min[2], S.root_max[0], S.root_max[1], S.root_max[2], t_max, t)) return false;
+        if (!root_tested && !slab(o, iw, S.root_min[0], S.root_min[1], S.root_min[2], S.root_max[0], S.root_max[1], S.root_max[2], t_max, t)) return false;
         co = o;
         cd = d;
         ci = iw;
@@ -537,8 +537,10 @@ struct Traversal {
 // chunk while its neighbours keep traversing (refill happens once at least kRefillMin lanes
 // are idle, so the reload code runs for a meaningful share of the wave).
 //   IO::kExactDistance                  done() reads the hit's distance (Traversal::op_level)
-//   io.load(i, o, d, tmax, tag)         ray i of the stream; tag travels with the ray to done()
-//   io.done(i, tag, trav, valid)        called once per ray by the lane that traced it
+//   IO::kStageCull                      rays that miss the scene's box are answered by io.miss() when they are read
+//   io.load(i, o, d, tmax, tag)         ray i of the stream; tag names the ray from here on (i itself, or a path slot)
+//   io.done(tag, trav, valid)           called once per ray by the lane that traced it
+//   io.miss(tag, tmax)                  kStageCull: the ray missed the scene's box (in place of done())
 //   io.flush()                          called by all 64 lanes at every refill point
 //   io.finish()                         called by all 64 lanes once, after the last flush
 constexpr uint32_t kFetchChunk = 256;
@@ -614,7 +616,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
     tr.in_blas = false;
     tr.sp = tr.base = 0;
     bool active = false;
-    uint32_t ray_index = 0, ray_tag = 0;
+    uint32_t ray_tag = 0;
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform
     uint32_t dry = 0;                      // wave-uniform: cursors found empty
     bool exhausted = false;                // wave-uniform
@@ -635,7 +637,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
     // Rays are read 64 at a time, by all lanes together, into the wave's LDS, and handed to lanes as
     // they fall idle: the wave then waits for a gather from path state (thousands of cycles when the
     // state does not fit the caches) once per 64 rays instead of at every refill.
-    uint32_t stage_base = 0, stage_next = 0, stage_end = 0;  // wave-uniform: staged rays are stream entries stage_base + [stage_next, stage_end)
+    uint32_t stage_next = 0, stage_end = 0;  // wave-uniform: staged entries [stage_next, stage_end) wait for a lane
     const uint32_t lane_id = threadIdx.x & 63u;
     for (;;) {
         int idle = count_lanes(!active);
@@ -651,13 +653,32 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
                     V3 o = mk3(0.0f, 0.0f, 0.0f), d = o;
                     float tmax = 0.0f;
                     uint32_t tag = 0;
-                    if (lane_id < count && !io.load(pool_next + lane_id, o, d, tmax, tag)) tmax = as_f(kNoRayBits);  // an unused slot of the stream
-                    stk.stage[lane_id] = v4f{o.x, o.y, o.z, tmax};
-                    stk.stage[kWave + lane_id] = v4f{d.x, d.y, d.z, as_f(tag)};
+                    if constexpr (IO::kStageCull) {
+                        // The test against the scene's box (kernel/intersection.h:162) runs here, for 64 rays at once, and
+                        // only the rays that pass are staged: a stream in which many rays miss the scene (camera rays)
+                        // then costs the lanes that refill no hand-outs that come to nothing.
+                        bool enters = false;
+                        if (lane_id < count && io.load(pool_next + lane_id, o, d, tmax, tag)) {
+                            float t;
+                            enters = slab(o, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), S.root_min[0], S.root_min[1], S.root_min[2], S.root_max[0], S.root_max[1],
+                                          S.root_max[2], tmax, t);
+                            if (!enters) io.miss(tag, tmax);
+                        }
+                        const uint64_t enter_mask = __ballot(enters);
+                        const uint32_t at = __builtin_amdgcn_mbcnt_hi(uint32_t(enter_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(enter_mask), 0u));
+                        if (enters) {
+                            stk.stage[at] = v4f{o.x, o.y, o.z, tmax};
+                            stk.stage[kWave + at] = v4f{d.x, d.y, d.z, as_f(tag)};
+                        }
+                        stage_end = uint32_t(__popcll(enter_mask));
+                    } else {
+                        if (lane_id < count && !io.load(pool_next + lane_id, o, d, tmax, tag)) tmax = as_f(kNoRayBits);  // an unused slot of the stream
+                        stk.stage[lane_id] = v4f{o.x, o.y, o.z, tmax};
+                        stk.stage[kWave + lane_id] = v4f{d.x, d.y, d.z, as_f(tag)};
+                        stage_end = count;
+                    }
                     __builtin_amdgcn_wave_barrier();
-                    stage_base = pool_next;
                     stage_next = 0;
-                    stage_end = count;
                     pool_next += count;
                 }
                 const uint64_t idle_mask = __ballot(!active);
@@ -666,11 +687,10 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
                 if (!active && entry < stage_end) {
                     PT_PHASE(ev, 5);
                     const v4f so = stk.stage[entry], sd = stk.stage[kWave + entry];
-                    if (as_u(so.w) != kNoRayBits) {
-                        ray_index = stage_base + entry;
+                    if (IO::kStageCull || as_u(so.w) != kNoRayBits) {
                         ray_tag = as_u(sd.w);
-                        if (tr.begin(S, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w)) active = true;
-                        else io.done(ray_index, ray_tag, tr, false);
+                        if (tr.begin(S, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), so.w, IO::kStageCull)) active = true;
+                        else io.done(ray_tag, tr, false);
                     }
                 }
                 const uint32_t wanted = uint32_t(__popcll(idle_mask));
@@ -700,9 +720,8 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
                     V3 o, d;
                     float tmax;
                     if (io.load(mine, o, d, tmax, ray_tag)) {  // false: an unused slot of the stream
-                        ray_index = mine;
                         if (tr.begin(S, o, d, tmax)) active = true;
-                        else io.done(ray_index, ray_tag, tr, false);
+                        else io.done(ray_tag, tr, false);
                     }
                 }
                 const uint32_t taken = uint32_t(idle);
@@ -815,7 +834,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
                     PT_PHASE(ev, 2);
                     if (tr.op_triangle(S)) {  // MODE_ANY only: occluded
                         active = false;
-                        io.done(ray_index, ray_tag, tr, true);
+                        io.done(ray_tag, tr, true);
                     }
                 }
                 n_tri = count_lanes(active && tr.wants_triangle());
@@ -837,7 +856,7 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
                 PT_PHASE(ev, 4);
                 if (tr.template op_level<IO::kExactDistance>(S)) {
                     active = false;
-                    io.done(ray_index, ray_tag, tr, MODE == MODE_ANY ? tr.found : tr.closest_valid());
+                    io.done(ray_tag, tr, MODE == MODE_ANY ? tr.found : tr.closest_valid());
                 }
             }
         }
