@@ -128,8 +128,10 @@ struct ClosestIO {
     }
     template <class TR>
     PTD void done(uint32_t i, const TR &tr, bool hit) const {
-        if (hit) store(i, tr.hit.t, tr.hit.u, tr.hit.v, int(tr.hit.prim), tr.hit.inst, int(tr.hit.mat));
-        else store(i, -1.0f, 0.0f, 0.0f, -1, -1, -1);
+        // one store site for hits and misses: the two halves of a record leave back to back and are merged on their way
+        // to memory (with a site per case the halves went out apart, and the memory side counted 61 bytes per record)
+        store(i, hit ? tr.hit.t : -1.0f, hit ? tr.hit.u : 0.0f, hit ? tr.hit.v : 0.0f, hit ? int(tr.hit.prim) : -1, hit ? tr.hit.inst : -1,
+              hit ? int(tr.hit.mat) : -1);
         if (COUNT) counters[i] = tr.ctr;
     }
     PTD void miss(uint32_t i, float) const {
