@@ -29,28 +29,14 @@
 #ifndef PT_ANY_CULL_MARGIN
 #define PT_ANY_CULL_MARGIN 2.44140625e-4f
 #endif
-#ifndef PT_STAGE_RAYS
-#define PT_STAGE_RAYS 1
-#endif
 #ifndef PT_STRAIGHT_PUSH
 #define PT_STRAIGHT_PUSH 1
-#endif
-#ifndef PT_POP_FIRST
-// 1: a lane without a node pops before the wave votes on the next box round and takes part in that round.
-// 0: the pop runs between the issue of the node loads and their use, where its LDS round trip is hidden, and
-// the lane joins one round later.  Measured on the bench's ray batch: 1 is 5-6 % faster in both layouts (a
-// ray spends 6 of its 34 steps popping); popping inside the box test itself, for lanes whose test hit no
-// child, costs the 4-wide kernel 16 more spilled registers and 12 %.
-#define PT_POP_FIRST 1
 #endif
 // Diagnostic builds that ask which resource the traversal responds to (tools/sensitivity.sh):
 //   -DPT_EXP_DOUBLE_LOAD  every 16-byte piece of a node of the box loop is requested a second time (one word,
 //                         issued with the node's own loads, used after the box test; the repeats hit the L1)
 //   -DPT_EXP_DOUBLE_VALU  the slab tests of a node are evaluated a second time on an opaque copy of the ray
 // Results are unchanged in both.
-#ifndef PT_POSTPONE_LEAVES
-#define PT_POSTPONE_LEAVES 0  // 1: lanes set leaves aside and keep testing boxes (see Traversal::kPostpone)
-#endif
 
 namespace ptd {
 
@@ -117,7 +103,6 @@ struct Traversal {
     bool in_blas;
     uint32_t cur;
     uint32_t tri_next, tri_left;  // progress inside the current BLAS leaf (tri_left == 0: not opened)
-    uint32_t held;   // a leaf set aside while the lane goes on testing boxes (kNoRef: none)
     HitRec hit;
     bool found;      // MODE_ANY: an occluder was found
     TraceCounters ctr;
@@ -159,40 +144,20 @@ struct Traversal {
         in_blas = false;
         cur = WIDE ? S.root_ref4 : S.root_ref;
         tri_next = tri_left = 0;
-        held = kNoRef;
         return true;
     }
 
     // True when a closest hit exists (valid once finished; kernel/intersection.h:229-232).
     PTD bool closest_valid() const { return !(best < 0.0f || best == FLT_MAX); }
 
-    // Leaves wait in a queue of up to three: the one being tested (tri_left > 0), `held`, and cur.
-    // With kPostpone a lane keeps popping and testing boxes while leaves wait (it only has to stop
-    // when cur is a leaf and `held` is taken): the bound used for culling is then a little stale, so
-    // a superset of the reference's nodes is visited, in the same order, and the leaves are still
-    // tested in the order they were met - the same triangle wins, ties included (only a ray that
-    // overflows the reference's 64-entry stack could tell the difference, because the set of
-    // dropped pushes depends on what was culled).  Measured on bounce rays: box rounds 0.43 -> 0.46
-    // of the lanes busy, 2 % faster; off by default for the overflow case.  The counting variant
-    // never postpones: its visit counts are the reference's.
-    static constexpr bool kPostpone = PT_POSTPONE_LEAVES && !COUNT;
-    PTD bool leaf_pending() const { return in_blas && (tri_left != 0 || held != kNoRef); }
     PTD bool wants_interior() const { return cur < kNoRef; }
     PTD bool wants_enter() const { return cur > kNoRef && !in_blas; }
-    // Without postponement cur keeps naming the leaf until its last triangle is done, so "cur is
-    // empty" alone says that no leaf is waiting.
-    PTD bool wants_triangle() const { return in_blas && (cur > kNoRef || (kPostpone && (tri_left != 0 || held != kNoRef))); }
+    // cur keeps naming the leaf until its last triangle is done, so "cur is empty" alone says that no leaf is waiting
+    PTD bool wants_triangle() const { return in_blas && cur > kNoRef; }
     PTD bool may_pop() const { return cur == kNoRef && sp != base; }
     PTD bool wants_pop() const { return may_pop() && sp <= DEPTH; }
     PTD bool wants_deep_pop() const { return may_pop() && sp > DEPTH; }  // entry is in the global spill area
-    PTD bool wants_level() const { return cur == kNoRef && sp == base && !(kPostpone && leaf_pending()); }
-    // cur is a leaf and `held` is free: set the leaf aside so that the lane can pop on
-    PTD void set_leaf_aside() {
-        if (kPostpone && in_blas && cur > kNoRef && held == kNoRef) {
-            held = cur;
-            cur = kNoRef;
-        }
-    }
+    PTD bool wants_level() const { return cur == kNoRef && sp == base; }
 
     // One pop (kernel/intersection.h:54-60): the entry is dropped when its box starts beyond
     // the current bound; then cur stays empty and the lane pops again next round.
@@ -384,17 +349,9 @@ struct Traversal {
     // The next triangle of the current leaf (kernel/intersection.h:63-112).  Returns true in
     // MODE_ANY when the ray is occluded (finished).
     PTD bool op_triangle(const DScene &S) {
-        if (tri_left == 0) {  // open the oldest waiting leaf
+        if (tri_left == 0) {  // open the leaf
             if (COUNT) ctr.blas_leaves++;
-            uint32_t leaf = cur;
-            if (kPostpone) {  // the leaf leaves the queue now; otherwise cur names it until it is done
-                if (held != kNoRef) {
-                    leaf = held;
-                    held = kNoRef;
-                } else {
-                    cur = kNoRef;
-                }
-            }
+            const uint32_t leaf = cur;
             tri_next = leaf & 0x0FFFFFFFu;
             tri_left = ((leaf >> 28) & 7u) + 1u;
             if (tri_left == 8u) {
@@ -428,7 +385,7 @@ struct Traversal {
                 lu = u;
                 lv = v;
                 tri_left = 0;
-                if (!kPostpone) cur = kNoRef;
+                cur = kNoRef;
                 return false;
             }
         } else if (ok && t < cbest) {
@@ -441,7 +398,7 @@ struct Traversal {
         }
         ++tri_next;
         --tri_left;
-        if (!kPostpone && tri_left == 0) cur = kNoRef;
+        if (tri_left == 0) cur = kNoRef;
         return false;
     }
 
@@ -560,9 +517,6 @@ constexpr uint32_t kNoRayBits = 0x7FC0DEADu;  // t_max bit pattern (a NaN no com
 #ifndef PT_VOTE_RARE
 #define PT_VOTE_RARE 8   // lanes that make an instance enter / level change round worth running
 #endif
-#ifndef PT_DRAIN_PRIO
-#define PT_DRAIN_PRIO 0  // wave priority (1-3) once the wave can no longer refill; 0: unchanged
-#endif
 #ifndef PT_VOTE_LEVEL
 #define PT_VOTE_LEVEL 12  // lanes that make a level change round worth running (8 / 12 / 16: 1.56 / 1.53 / 1.54 ms on the bench batch)
 #endif
@@ -620,9 +574,6 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform
     uint32_t dry = 0;                      // wave-uniform: cursors found empty
     bool exhausted = false;                // wave-uniform
-#if PT_DRAIN_PRIO
-    bool boosted = false;                  // wave-uniform
-#endif
 #ifdef PT_TRACE_STAMPS
     unsigned long long tstamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tstamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstamp_last)::"memory");
@@ -633,7 +584,6 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
 #ifdef PT_EXP_DOUBLE_LOAD
     float dup_word[kNodeRegs];
 #endif
-#if PT_STAGE_RAYS
     // Rays are read 64 at a time, by all lanes together, into the wave's LDS, and handed to lanes as
     // they fall idle: the wave then waits for a gather from path state (thousands of cycles when the
     // state does not fit the caches) once per 64 rays instead of at every refill.
@@ -703,58 +653,20 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
         }
         const bool can_refill = !(exhausted && pool_next >= pool_end && stage_next == stage_end);  // wave-uniform
         idle = count_lanes(!active);
-#else
-    for (;;) {
-        const uint64_t idle_mask = __ballot(!active);
-        const int idle = __popcll(idle_mask);
-        if (idle >= kRefillMin || idle == kWave) {
-            io.flush();
-            if (pool_next >= pool_end && !exhausted) {
-                if (!fetch_rays(feed, n, dry, pool_next, pool_end)) exhausted = dry >= feed.groups;
-            }
-            if (pool_next < pool_end) {
-                const uint32_t prefix = __builtin_amdgcn_mbcnt_hi(uint32_t(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle_mask), 0u));
-                const uint32_t mine = pool_next + prefix;
-                if (!active && mine < pool_end) {
-                    PT_PHASE(ev, 5);
-                    V3 o, d;
-                    float tmax;
-                    if (io.load(mine, o, d, tmax, ray_tag)) {  // false: an unused slot of the stream
-                        if (tr.begin(S, o, d, tmax)) active = true;
-                        else io.done(ray_tag, tr, false);
-                    }
-                }
-                const uint32_t taken = uint32_t(idle);
-                pool_next = (pool_end - pool_next < taken) ? pool_end : pool_next + taken;
-            } else if (exhausted && idle == kWave) {
-                break;
-            }
-        }
-        const bool can_refill = !(exhausted && pool_next >= pool_end);  // wave-uniform
-#endif
-#if PT_DRAIN_PRIO
-        // A wave that can no longer refill only has the ends of its longest rays left, and the launch ends with the
-        // last of them: from here on its instructions go before those of waves that still have rays to take.
-        if (!can_refill && !boosted) {
-            __builtin_amdgcn_s_setprio(PT_DRAIN_PRIO);
-            boosted = true;
-        }
-#endif
         PT_PHASE(ev, 7);
         PT_TSTAMP(5);
 
-        // ---- box-test rounds, while enough lanes take part (PT_POP_FIRST says where the pops go)
+        // ---- box-test rounds, while enough lanes take part.  A lane without a node pops before the vote and takes part
+        // in the round (popping between the issue of the node loads and their use, where the LDS round trip would be
+        // hidden, makes the lane join one round later: 5-6 % slower on the bench batch)
         const unsigned long long active_mask = __builtin_amdgcn_ballot_w64(active);
         // a wave that can no longer refill keeps the loop going for half of the lanes it has left
         const int vote_int = (PT_DRAIN_ALL_OPS && !can_refill) ? max(1, (__builtin_popcountll(active_mask) + 1) >> 1) : PT_VOTE_INT;
         for (;;) {
-            if (active) tr.set_leaf_aside();
-#if PT_POP_FIRST
             if (active && tr.wants_pop()) {
                 PT_PHASE(ev, 3);
                 tr.pop(stk);
             }
-#endif
             const unsigned long long int_mask = __builtin_amdgcn_ballot_w64(tr.wants_interior()) & active_mask;
             const bool w_int = active && tr.wants_interior();
             const bool go = __builtin_popcountll(int_mask) >= vote_int;
@@ -770,12 +682,6 @@ PTD void trace_stream(const DScene &S, IO &io, uint32_t n, const WorkFeed &feed,
                 for (int r = 0; r < kNodeRegs; ++r) asm volatile("global_load_dword %0, %1, off offset:4" : "=v"(dup_word[r]) : "v"(np + r));  // a plain cached load the compiler cannot merge
 #endif
             }
-#if !PT_POP_FIRST
-            if (active && tr.wants_pop()) {
-                PT_PHASE(ev, 3);
-                tr.pop(stk);
-            }
-#endif
             PT_TSTAMP_NOWAIT(0);
             if (!go) break;
             PT_TSTAMP(1);
