@@ -447,9 +447,6 @@ __global__ __launch_bounds__(64, PT_EXTEND_WAVES_PER_SIMD) void k_extend(DScene 
 #ifndef PT_SHADE_GROUP
 #define PT_SHADE_GROUP 16
 #endif
-#ifndef PT_SHADE_STATIC
-#define PT_SHADE_STATIC 0
-#endif
 constexpr uint32_t kShadeGroup = PT_SHADE_GROUP;
 
 // Diagnostic build only (-DPT_PHASE_PROF -DPT_SHADE_STAMPS): wave clock spent between the marked
@@ -487,17 +484,10 @@ __global__ __launch_bounds__(64) void k_shade(DScene S, PathState P, BounceCount
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
 #endif
-#if PT_SHADE_STATIC
-    for (uint32_t round = 0;; ++round) {
-      PT_STAMP(7);
-      const uint32_t first_chunk = (round * gridDim.x + blockIdx.x) * group;  // shading a chunk costs about the same everywhere
-      if (first_chunk >= total_chunks) break;
-#else
     for (;;) {
       PT_STAMP(7);
       const uint32_t first_chunk = wave_fetch(&bc->cur_shade, group);
       if (first_chunk >= total_chunks) break;
-#endif
       const uint32_t end_chunk = (total_chunks - first_chunk < group) ? total_chunks : first_chunk + group;
       uint32_t n_ext = 0, n_sh = 0;  // wave-uniform fill levels of the staging areas
       for (uint32_t chunk = first_chunk; chunk < end_chunk; ++chunk) {

@@ -29,9 +29,6 @@
 #ifndef PT_ANY_CULL_MARGIN
 #define PT_ANY_CULL_MARGIN 2.44140625e-4f
 #endif
-#ifndef PT_STRAIGHT_PUSH
-#define PT_STRAIGHT_PUSH 1
-#endif
 // Diagnostic builds that ask which resource the traversal responds to (tools/sensitivity.sh):
 //   -DPT_EXP_DOUBLE_LOAD  every 16-byte piece of a node of the box loop is requested a second time (one word,
 //                         issued with the node's own loads, used after the box test; the repeats hit the L1)
@@ -200,7 +197,6 @@ struct Traversal {
         const int depth = sp - base;
         const bool both = hl && hr;
         const bool left_first = tl < tr;
-#if PT_STRAIGHT_PUSH
         // Usual case, decided for the wave as a whole: no lane is near the reference's 64-entry limit
         // or the end of the LDS part of the stack.  Then the push is straight-line code: the far
         // child is written above the top of the stack unconditionally and only counted when both
@@ -215,7 +211,6 @@ struct Traversal {
             cur = (hl || hr) ? near_ref : kNoRef;
             return;
         }
-#endif
         if (__builtin_expect(depth < kRefStack - 1, 1)) {
             if (both) {
                 stack_store(stk, sp, left_first ? rref : lref, left_first ? tr : tl, ev);
